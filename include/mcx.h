@@ -1,0 +1,192 @@
+/* mcx.h -- C ABI of libmcx.so, the MI355X (gfx950) runtime behind
+ * MonteCarloIntegrator.{integrate, integrate_importance_sampling, integrate_mcmc}.
+ *
+ * It replaces the reference's PyO3 module `wgpu_montecarlo._core` (src/lib.rs) together with the
+ * Rust layers under it (src/engine.rs device runtime, src/shader_gen.rs kernel assembler,
+ * src/distribution.rs device library). Every entry point cites the reference interface it
+ * replaces (file:line into NightingaleCen/wgpu-monte-carlo). Plain pointers and sizes only.
+ *
+ * Conventions: every function returns 0 on success or a negative MCX_E_* code; the text of the
+ * last error of the calling thread is available from mcx_last_error(). Host pointers passed in
+ * are only read during the call. Handles are owned by the caller and released with the matching
+ * *_destroy / *_release call. One engine drives one GPU; calls on one engine are serialised by
+ * an internal mutex.
+ */
+#ifndef MCX_H
+#define MCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCX_OK              0
+#define MCX_E_INVALID      -1   /* bad argument (Python side raises ValueError)                 */
+#define MCX_E_RUNTIME      -2   /* HIP runtime failure (RuntimeError)                           */
+#define MCX_E_COMPILE      -3   /* hiprtc failure, log in mcx_last_error() (RuntimeError)       */
+#define MCX_E_NODEVICE     -4   /* no usable GPU (RuntimeError "Failed to initialize GPU: ..")  */
+
+/* distribution type codes: DistributionParamsBuffer.dist_type, src/engine.rs:32-37, src/lib.rs:436-502 */
+#define MCX_DIST_UNIFORM     0
+#define MCX_DIST_NORMAL      1
+#define MCX_DIST_EXPONENTIAL 2
+#define MCX_DIST_CUSTOM      3
+
+/* table kinds */
+#define MCX_TABLE_CDF     0   /* keys = cdf, values = x  : sample_from_cdf_table, distribution.rs:128-158 */
+#define MCX_TABLE_PDF     1   /* keys = x, values = pdf  : pdf_*_from_table, distribution.rs:181-275      */
+#define MCX_TABLE_LOGPDF  2   /* keys = x, values = log pdf : log_pdf_*_from_table, distribution.rs:375-469 */
+
+typedef struct mcx_engine mcx_engine;
+typedef struct mcx_module mcx_module;
+typedef struct mcx_table  mcx_table;
+
+const char* mcx_version(void);
+const char* mcx_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Planning -- pure host arithmetic, usable without a GPU.
+ * ------------------------------------------------------------------------------------------ */
+
+/* DispatchConfig, src/engine.rs:39-46 */
+typedef struct mcx_dispatch {
+    uint32_t workgroup_size;     /* always 256 */
+    uint32_t workgroup_count;
+    uint32_t loops_per_thread;   /* L */
+    uint32_t total_threads;      /* T */
+} mcx_dispatch;
+
+/* ComputeEngine::calculate_dispatch_config, src/engine.rs:157-181.
+ * target_threads <= 0 selects the reference default 65536. L is the truncating u32 cast of
+ * ceil(n_samples / T), as in the reference. */
+int mcx_dispatch_config(uint64_t n_samples, int64_t target_threads, mcx_dispatch* out);
+
+/* ComputeEngine::calculate_mcmc_dispatch_config + setup_mcmc, src/engine.rs:821-832, 860-866:
+ * chains = target_threads if > 0 else n_chains, padded up to a multiple of 256; the padded
+ * count is what runs and what is averaged. */
+int mcx_mcmc_dispatch_config(uint32_t n_chains, int64_t target_threads, mcx_dispatch* out);
+
+/* One rank's share of the logical sample grid {(idx, i): idx < T, i < L} (new; the reference is
+ * single-device). Units are loop iterations i, or Box-Muller pairs (2j, 2j+1) for the normal
+ * distribution, so that a shard boundary never splits a pair. The union over ranks is exactly the
+ * single-GPU grid. */
+typedef struct mcx_shard {
+    uint32_t idx_begin, idx_count;
+    uint32_t unit_begin, unit_end;
+} mcx_shard;
+int mcx_shard_integrate(const mcx_dispatch* d, int dist_type, uint32_t rank, uint32_t world, mcx_shard* out);
+
+/* One rank's contiguous share of the padded chain range [0, T), in multiples of 256 chains. */
+int mcx_shard_chains(uint32_t total_chains, uint32_t rank, uint32_t world,
+                     uint32_t* chain_begin, uint32_t* chain_count);
+
+/* ------------------------------------------------------------------------------------------
+ * Engine -- replaces ComputeEngine::new, src/engine.rs:91-131 / _core.MonteCarloIntegrator(), src/lib.rs:24-31
+ * ------------------------------------------------------------------------------------------ */
+int  mcx_device_count(void);                         /* 0 when no GPU is visible */
+int  mcx_engine_create(int device, mcx_engine** out);
+void mcx_engine_destroy(mcx_engine* e);
+int  mcx_engine_device(const mcx_engine* e);
+/* Duration in ms of the main (sampling) kernel of the last call on this engine, measured with
+ * HIP events on the stream it was launched on; < 0 if nothing was launched. */
+float mcx_engine_last_kernel_ms(mcx_engine* e);
+/* Launch geometry of the last call: physical workgroups, threads per workgroup, dynamic LDS bytes. */
+int  mcx_engine_last_launch(mcx_engine* e, uint32_t* n_blocks, uint32_t* block, uint32_t* lds_bytes);
+/* Tuning knob: physical threads a launch aims for (default 256 CUs x 2048 x 2). */
+int  mcx_engine_set_target_threads(mcx_engine* e, uint32_t physical_threads);
+
+/* ------------------------------------------------------------------------------------------
+ * Modules -- replaces generate_*_shader (src/shader_gen.rs:45, 134, 312) +
+ * create_*_pipeline (src/engine.rs:325, 621, 1022): the emitted user functions are fused into
+ * the hand-written kernel skeleton and compiled for gfx950 with hiprtc. Unlike the reference,
+ * which recompiles on every call, code objects are cached by source hash (memory + disk).
+ * ------------------------------------------------------------------------------------------ */
+#define MCX_KIND_INTEGRATE 0   /* K1 / K2 */
+#define MCX_KIND_MCMC      1   /* K3 */
+
+typedef struct mcx_module_desc {
+    int32_t kind;              /* MCX_KIND_* */
+    int32_t k;                 /* number of fused user functions user_func_0 .. user_func_{k-1} */
+    int32_t dist_type;         /* sampling (K1/K2) or proposal (K3) distribution */
+    int32_t weight;            /* 1: importance weight p/q applied (K2) */
+    int32_t p_table;           /* 1: target pdf from table, 0: analytic mcx_pdf_p in user_src */
+    int32_t q_table;           /* 1: proposal pdf from table, 0: analytic mcx_pdf_q in user_src */
+    int32_t guard_endpoints;   /* 1 (default): u in (0,1] / [0,1); 0: strict reference u = float(h)*2^-32 */
+    int32_t precise_sampler;   /* 1: ocml log/sin/cos in the samplers; 0: v_log/v_sin/v_cos */
+    int32_t block;             /* threads per workgroup: 0 = auto (256, or 1024 when tables are staged) */
+    int32_t tables_lds;        /* 1 (default): tables staged in LDS; 0: read from HBM/L2 */
+} mcx_module_desc;
+
+/* user_src: HIP C++ text defining `__device__ float user_func_i(float x)` for i < k (and
+ * mcx_pdf_p / mcx_pdf_q when weight && !p_table / !q_table). */
+int  mcx_module_build(mcx_engine* e, const char* user_src, const mcx_module_desc* desc, mcx_module** out);
+/* hiprtc compile into the on-disk cache only: needs no GPU. cache_hit may be NULL. */
+int  mcx_module_precompile(const char* user_src, const mcx_module_desc* desc, int* cache_hit);
+/* Full translation unit that would be compiled (for inspection / offline hipcc). Caller frees with mcx_free. */
+int  mcx_module_source(const char* user_src, const mcx_module_desc* desc, char** out_text);
+void mcx_free(void* p);
+void mcx_module_release(mcx_module* m);
+/* Where code objects are cached (default: <dir of libmcx.so>/jit_cache, override MCX_CACHE_DIR). */
+const char* mcx_cache_dir(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Tables -- replaces the storage buffers of setup_integration / create_interleaved_pdf_buffer /
+ * setup_mcmc (src/engine.rs:235-295, 533-564, 963-989). Uploaded once, resident in HBM.
+ * ------------------------------------------------------------------------------------------ */
+int  mcx_table_create(mcx_engine* e, int kind, const float* keys, const float* values, uint32_t n, mcx_table** out);
+void mcx_table_release(mcx_table* t);
+/* Host-side analysis results (also usable in tests): uniform-grid flag and guide-table bits. */
+int  mcx_table_info(const mcx_table* t, uint32_t* n, float* inv_dk, uint32_t* guide_bits);
+
+/* ------------------------------------------------------------------------------------------
+ * Integration -- replaces _core.MonteCarloIntegrator.integrate (src/lib.rs:47-141) and
+ * .integrate_is_tables (src/lib.rs:158-275): setup -> execute -> reduce.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mcx_integrate_params {
+    uint64_t n_samples;          /* requested; rounded UP to T*L like the reference */
+    int64_t  target_threads;     /* <= 0: default 65536 */
+    uint32_t seed;
+    float    param1, param2;     /* uniform (min,max) / normal (mean,std) / exponential (lambda,-) */
+    uint32_t rank, world;        /* shard selector; world = 1 for the whole grid */
+    const mcx_table* cdf;        /* MCX_TABLE_CDF, custom distribution only */
+    const mcx_table* target_pdf;   /* MCX_TABLE_PDF when desc.p_table */
+    const mcx_table* proposal_pdf; /* MCX_TABLE_PDF when desc.q_table */
+} mcx_integrate_params;
+
+/* sums_out[k] = sum over this rank's shard of f_k(x) (*p/q); n_eff_out = T*L of the WHOLE grid.
+ * The reference's return value is sums / n_eff (mean of per-thread means of equal length). */
+int mcx_integrate(mcx_engine* e, mcx_module* m, const mcx_integrate_params* p,
+                  double* sums_out, uint64_t* n_eff_out);
+/* Same, but the K sums are left in device memory at d_sums (K doubles) and the work is enqueued
+ * on `stream` (a hipStream_t; NULL = the engine's own stream) without a host sync: the caller
+ * runs the collective (RCCL all-reduce) on the same stream. */
+int mcx_integrate_device(mcx_engine* e, mcx_module* m, const mcx_integrate_params* p,
+                         void* d_sums, void* stream, uint64_t* n_eff_out);
+
+/* ------------------------------------------------------------------------------------------
+ * MCMC -- replaces _core.MonteCarloIntegrator.integrate_mcmc (src/lib.rs:296-431).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mcx_mcmc_params {
+    uint32_t n_steps, n_chains, n_burnin;
+    int64_t  target_threads;     /* > 0 overrides n_chains (src/engine.rs:860) */
+    uint32_t seed;
+    float    param1, param2;     /* proposal parameters */
+    uint32_t rank, world;
+    const mcx_table* cdf;              /* custom proposal */
+    const mcx_table* target_logpdf;    /* MCX_TABLE_LOGPDF, required */
+    const mcx_table* proposal_logpdf;  /* MCX_TABLE_LOGPDF, required */
+} mcx_mcmc_params;
+
+/* sums_out[0..k) = sum over this rank's chains and all sampling steps of f_k(x_t);
+ * sums_out[k] = number of accepted steps (burn-in included); n_eff_out = padded chains * n_steps. */
+int mcx_mcmc(mcx_engine* e, mcx_module* m, const mcx_mcmc_params* p,
+             double* sums_out, uint64_t* n_eff_out);
+int mcx_mcmc_device(mcx_engine* e, mcx_module* m, const mcx_mcmc_params* p,
+                    void* d_sums, void* stream, uint64_t* n_eff_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCX_H */

@@ -1,0 +1,403 @@
+/* mcx_oracle.c -- CPU restatement of the reference's Monte-Carlo kernels.
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing under oracle/ is imported, linked or executed by the product
+ * (wgpu-monte-carlo_amd/); only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * use it, and only as the checker / the timed CPU baseline.
+ *
+ * What it restates (file:line into NightingaleCen/wgpu-monte-carlo, /root/reference here):
+ *   pcg_hash, random_uniform            src/distribution.rs:62-73
+ *   sample_uniform                      src/distribution.rs:80-82
+ *   sample_normal_box_muller + cache    src/distribution.rs:87-114
+ *   sample_exponential                  src/distribution.rs:120-124
+ *   sample_from_cdf_table               src/distribution.rs:128-158
+ *   pdf_* / log_pdf_*_from_table        src/distribution.rs:181-223, 375-417 (+ interleaving engine.rs:533-564)
+ *   K1/K2 kernel body + epilogue        src/shader_gen.rs:93-117, 293-303
+ *   K3 kernel, init, step, epilogue     src/shader_gen.rs:396-428, 445-463, 511-537, 574-579
+ *   dispatch sizing                     src/engine.rs:157-181, 821-832, 860-866
+ *   host mean over threads (f32, sequential)   src/lib.rs:129-138
+ *   IS wrapper algebra f*p/q            python/wgpu_montecarlo/__init__.py:893-899, 968-974
+ *
+ * Parity status: the integer side (dispatch sizes, counters, pcg_hash outputs) is pinned by the
+ * reference source itself; the floating-point side of the reference executes inside
+ * naga 23.1.0 -> {Metal, Vulkan, DX12} driver compilers (Cargo.lock:496-497, 1018-1019), whose
+ * log/sin/cos/pow/division precision is implementation-defined and which cannot be built or run
+ * here (no Rust, no wgpu, no GPU API). The reference's tests hold NO numeric golden vectors for
+ * this path, only statistical tolerances against analytic truth (tests/test_integrator.py:181-257,
+ * tests/test_distributions.py:78-110, tests/test_mcmc.py:91-148); this oracle is pinned against
+ * those (tests/test_oracle_pins.py). Float parity beyond those tolerances is UNPINNED.
+ *
+ * Arithmetic: f32 everywhere the WGSL is f32 (compile with -ffp-contract=off so that a*b+c is
+ * two roundings), libm logf/sqrtf/sinf/cosf/expf/powf for the WGSL builtins, u32 wrapping.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_DIST_UNIFORM 0
+#define ORC_DIST_NORMAL 1
+#define ORC_DIST_EXPONENTIAL 2
+#define ORC_DIST_CUSTOM 3
+
+/* ---------------------------------------------------------------- RNG (distribution.rs:62-73) */
+uint32_t orc_pcg_hash(uint32_t v) {
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+
+uint32_t orc_combined(uint32_t seed, uint32_t idx, uint32_t iter) {
+    return seed + idx * 7199369u + iter * 15485863u;
+}
+
+/* f32(hashed) / 4294967295.0 : the literal is not representable in f32 and rounds to 2^32 */
+float orc_random_uniform(uint32_t seed, uint32_t idx, uint32_t iter) {
+    uint32_t h = orc_pcg_hash(orc_combined(seed, idx, iter));
+    return (float)h / 4294967296.0f;
+}
+
+/* ---------------------------------------------------------------- dispatch (engine.rs:157-181, 821-832, 860) */
+void orc_dispatch_config(uint64_t n_samples, int64_t target_threads, uint32_t out[4]) {
+    uint32_t target = target_threads > 0 ? (uint32_t)target_threads : 65536u;
+    uint32_t wg = 256u;
+    uint32_t wgc = (target + wg - 1u) / wg;
+    uint32_t total = wgc * wg;
+    uint32_t loops = (uint32_t)((n_samples + (uint64_t)total - 1ull) / (uint64_t)total);
+    out[0] = wg; out[1] = wgc; out[2] = loops; out[3] = total;
+}
+
+void orc_mcmc_dispatch_config(uint32_t n_chains, int64_t target_threads, uint32_t out[4]) {
+    uint32_t chains = target_threads > 0 ? (uint32_t)target_threads : n_chains;
+    uint32_t wg = 256u;
+    uint32_t wgc = (chains + wg - 1u) / wg;
+    out[0] = wg; out[1] = wgc; out[2] = 1u; out[3] = wgc * wg;
+}
+
+/* ---------------------------------------------------------------- samplers */
+typedef struct {
+    int has_cached;      /* var<private> has_cached_normal (distribution.rs:88) */
+    float cached;        /* var<private> normal_cached     (distribution.rs:87) */
+} orc_bm_state;
+
+/* guard: 0 = strict reference; 1 = libmcx default endpoint guards (u1 = 2^-33 when the hash is 0,
+ * u < 1 for the uniform distribution's affine map). The guards change a sample only when the
+ * hash output is 0 resp. >= 0xFFFFFF80. */
+static float u_from_hash(uint32_t h) { return (float)h / 4294967296.0f; }
+
+static float orc_sample_uniform(float rng, float lo, float hi) { return lo + rng * (hi - lo); }
+
+static float orc_sample_normal(orc_bm_state* st, uint32_t seed, uint32_t idx, uint32_t iter, float mean,
+                               float sigma, int guard) {
+    if (st->has_cached) {
+        st->has_cached = 0;
+        return mean + sigma * st->cached;
+    }
+    uint32_t h1 = orc_pcg_hash(orc_combined(seed, idx, iter * 2u));
+    uint32_t h2 = orc_pcg_hash(orc_combined(seed, idx, iter * 2u + 1u));
+    float u1 = u_from_hash(h1);
+    if (guard && h1 == 0u) u1 = 0x1.0p-33f;
+    float u2 = u_from_hash(h2);
+    float r = sqrtf(-2.0f * logf(u1));
+    float theta = 6.283185307179586f * u2;
+    float z0 = r * cosf(theta);
+    float z1 = r * sinf(theta);
+    st->cached = z1;
+    st->has_cached = 1;
+    return mean + sigma * z0;
+}
+
+static float orc_sample_exponential(float rng, float lambda) {
+    float u = fmaxf(rng, 1.0e-7f);
+    return -logf(u) / lambda;
+}
+
+static float orc_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
+static float orc_sample_from_cdf_table(float rng, uint32_t n, const float* cdf, const float* xt) {
+    uint32_t low = 0u, high = n - 1u;
+    for (uint32_t j = 0u; j < 12u; j++) {
+        if (low >= high) break;
+        uint32_t mid = (low + high) / 2u;
+        if (cdf[mid] < rng) low = mid + 1u; else high = mid;
+    }
+    uint32_t il = (low > 1u ? low : 1u) - 1u;
+    uint32_t ih = low < n - 1u ? low : n - 1u;
+    float cl = cdf[il], ch = cdf[ih], xl = xt[il], xh = xt[ih];
+    if (ch - cl < 1.0e-10f) return xl;
+    float t = (rng - cl) / (ch - cl);
+    return orc_mix(xl, xh, t);
+}
+
+/* interleaved [n, x0, v0, x1, v1, ...] exactly as engine.rs:544-551 builds it */
+static float orc_table_lookup(const float* data, float x, float outside) {
+    uint32_t n = (uint32_t)data[0];
+    float x_min = data[1];
+    float x_max = data[1u + (n - 1u) * 2u];
+    if ((x < x_min) || (x > x_max)) return outside;
+    uint32_t low = 0u, high = n - 1u;
+    for (uint32_t j = 0u; j < 16u; j++) {
+        if (low >= high) break;
+        uint32_t mid = (low + high) / 2u;
+        if (data[1u + mid * 2u] < x) low = mid + 1u; else high = mid;
+    }
+    low = (low > 1u ? low : 1u) - 1u;
+    low = low < n - 2u ? low : n - 2u;
+    float xl = data[1u + low * 2u], xh = data[1u + (low + 1u) * 2u];
+    float vl = data[2u + low * 2u], vh = data[2u + (low + 1u) * 2u];
+    float dx = xh - xl;
+    if (dx < 1.0e-10f) return vl;
+    float t = (x - xl) / dx;
+    return orc_mix(vl, vh, t);
+}
+
+float orc_table_lookup_xy(const float* xs, const float* vs, uint32_t n, float x, float outside) {
+    float* data = (float*)malloc((1u + 2u * (size_t)n) * sizeof(float));
+    data[0] = (float)n;
+    for (uint32_t i = 0; i < n; ++i) { data[1u + 2u * i] = xs[i]; data[2u + 2u * i] = vs[i]; }
+    float r = orc_table_lookup(data, x, outside);
+    free(data);
+    return r;
+}
+
+float orc_sample_cdf(float rng, uint32_t n, const float* cdf, const float* xt) {
+    return orc_sample_from_cdf_table(rng, n, cdf, xt);
+}
+
+/* ---------------------------------------------------------------- user functions (a fixed menu) */
+#define ORC_FN_IDENTITY 0   /* x */
+#define ORC_FN_POW      1   /* pow(x, a)   -- what `x**a` transpiles to (transpiler.py:715-716) */
+#define ORC_FN_SIN      2
+#define ORC_FN_COS      3
+#define ORC_FN_EXP      4
+#define ORC_FN_GT       5   /* select(0,1, x > a) */
+#define ORC_FN_BENCH    6   /* x / (exp(sin(x)) + cos(exp(x)))  examples/benchmark.py:8-13 */
+#define ORC_FN_ABS      7
+#define ORC_FN_CONST    8   /* a */
+#define ORC_FN_SQ       9   /* x * x */
+
+typedef struct { int32_t kind; float a; } orc_fn;
+
+static float eval_fn(const orc_fn* f, float x) {
+    switch (f->kind) {
+        case ORC_FN_IDENTITY: return x;
+        case ORC_FN_POW: return powf(x, f->a);
+        case ORC_FN_SIN: return sinf(x);
+        case ORC_FN_COS: return cosf(x);
+        case ORC_FN_EXP: return expf(x);
+        case ORC_FN_GT: return x > f->a ? 1.0f : 0.0f;
+        case ORC_FN_BENCH: return x / (expf(sinf(x)) + cosf(expf(x)));
+        case ORC_FN_ABS: return fabsf(x);
+        case ORC_FN_CONST: return f->a;
+        case ORC_FN_SQ: return x * x;
+        default: return NAN;
+    }
+}
+
+/* analytic PDFs as the reference's Distribution closures transpile (python/wgpu_montecarlo/__init__.py:317-318, 345-347, 374-375) */
+#define ORC_PDF_NONE        0
+#define ORC_PDF_UNIFORM     1   /* select(0.0, 1.0/width, (min <= x) && (x < max)); a=min b=max c=width */
+#define ORC_PDF_NORMAL      2   /* z=(x-mean)/sigma; exp(-0.5*z*z)/(sigma*sqrt_2pi); a=mean b=sigma c=sqrt_2pi */
+#define ORC_PDF_EXPONENTIAL 3   /* select(0.0, lambda*exp((-lambda)*x), x >= 0.0); a=lambda */
+#define ORC_PDF_TABLE       4   /* pdf_*_from_table over interleaved data */
+
+typedef struct { int32_t kind; float a, b, c; const float* table; /* interleaved [n,x0,v0,...] */ } orc_pdf;
+
+static float eval_pdf(const orc_pdf* p, float x) {
+    switch (p->kind) {
+        case ORC_PDF_UNIFORM: return ((p->a <= x) && (x < p->b)) ? (1.0f / p->c) : 0.0f;
+        case ORC_PDF_NORMAL: { float z = (x - p->a) / p->b; return expf(((-0.5f) * z) * z) / (p->b * p->c); }
+        case ORC_PDF_EXPONENTIAL: return (x >= 0.0f) ? (p->a * expf((-p->a) * x)) : 0.0f;
+        case ORC_PDF_TABLE: return orc_table_lookup(p->table, x, 0.0f);
+        default: return 1.0f;
+    }
+}
+
+/* ---------------------------------------------------------------- K1 / K2 */
+typedef struct {
+    uint64_t n_samples;
+    int64_t  target_threads;
+    uint32_t seed;
+    int32_t  dist_type;
+    float    param1, param2;
+    uint32_t table_size;
+    const float* cdf_table;   /* lookup_table binding */
+    const float* x_table;     /* x_table binding */
+    int32_t  guard;           /* 0 strict reference, 1 libmcx default guards */
+    int32_t  weighted;        /* 1: f*p/q */
+    orc_pdf  p, q;
+} orc_k1_args;
+
+static float k1_sample(const orc_k1_args* a, orc_bm_state* bm, uint32_t idx, uint32_t i) {
+    if (a->dist_type == ORC_DIST_NORMAL)
+        return orc_sample_normal(bm, a->seed, idx, i, a->param1, a->param2, a->guard);
+    uint32_t h = orc_pcg_hash(orc_combined(a->seed, idx, i));
+    float rng = u_from_hash(h);
+    if (a->dist_type == ORC_DIST_UNIFORM) {
+        if (a->guard && rng >= 1.0f) rng = 0x1.fffffep-1f;
+        return orc_sample_uniform(rng, a->param1, a->param2);
+    }
+    if (a->dist_type == ORC_DIST_EXPONENTIAL) return orc_sample_exponential(rng, a->param1);
+    return orc_sample_from_cdf_table(rng, a->table_size, a->cdf_table, a->x_table);
+}
+
+/* Exact restatement: out_ref[k] is what the reference returns (f32 per-thread accumulate, f32 divide by
+ * L, sequential f32 sum over T, f32 divide by T). out_sum64[k] is the f64 sum of the same f32 term
+ * values over the whole grid (what libmcx's f64 reduction computes, up to summation order). */
+int orc_k1(const orc_k1_args* a, const orc_fn* fns, int K, float* out_ref, double* out_sum64, uint64_t* n_eff) {
+    uint32_t cfg[4];
+    orc_dispatch_config(a->n_samples, a->target_threads, cfg);
+    const uint32_t L = cfg[2], T = cfg[3];
+    if (n_eff) *n_eff = (uint64_t)T * (uint64_t)L;
+    float* out = (float*)malloc((size_t)T * K * sizeof(float));
+    double* s64 = (double*)calloc((size_t)T * K, sizeof(double));
+    if (!out || !s64) { free(out); free(s64); return -1; }
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < (int64_t)T; ++t) {
+        uint32_t idx = (uint32_t)t;
+        orc_bm_state bm = {0, 0.0f};
+        float acc[64];
+        double acc64[64];
+        for (int k = 0; k < K; ++k) { acc[k] = 0.0f; acc64[k] = 0.0; }
+        for (uint32_t i = 0u; i < L; i = i + 1u) {
+            float x = k1_sample(a, &bm, idx, i);
+            float w_p = 1.0f, w_q = 1.0f;
+            if (a->weighted) { w_p = eval_pdf(&a->p, x); w_q = eval_pdf(&a->q, x); }
+            for (int k = 0; k < K; ++k) {
+                float f = eval_fn(&fns[k], x);
+                float term = a->weighted ? (f * w_p / w_q) : f;    /* f_val * p / q, left-assoc */
+                acc[k] += term;
+                acc64[k] += (double)term;
+            }
+        }
+        for (int k = 0; k < K; ++k) {
+            out[(size_t)idx * K + k] = acc[k] / (float)L;           /* shader_gen.rs:297 */
+            s64[(size_t)idx * K + k] = acc64[k];
+        }
+    }
+    for (int k = 0; k < K; ++k) {                                    /* lib.rs:133-137 */
+        float sum = 0.0f;
+        double sum64 = 0.0;
+        for (uint32_t t = 0; t < T; ++t) { sum += out[(size_t)t * K + k]; sum64 += s64[(size_t)t * K + k]; }
+        if (out_ref) out_ref[k] = sum / (float)T;
+        if (out_sum64) out_sum64[k] = sum64;
+    }
+    free(out); free(s64);
+    return 0;
+}
+
+/* Dump the samples x(idx, i) for idx in [idx0, idx0+nidx), i in [0, L): out[(idx-idx0)*L + i]. */
+int orc_k1_samples(const orc_k1_args* a, uint32_t idx0, uint32_t nidx, float* out) {
+    uint32_t cfg[4];
+    orc_dispatch_config(a->n_samples, a->target_threads, cfg);
+    const uint32_t L = cfg[2];
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < (int64_t)nidx; ++t) {
+        uint32_t idx = idx0 + (uint32_t)t;
+        orc_bm_state bm = {0, 0.0f};
+        for (uint32_t i = 0u; i < L; ++i) out[(size_t)t * L + i] = k1_sample(a, &bm, idx, i);
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- K3 */
+typedef struct {
+    uint32_t n_steps, n_chains, n_burnin;
+    int64_t  target_threads;
+    uint32_t seed;
+    int32_t  proposal_type;
+    float    param1, param2;
+    uint32_t table_size;
+    const float* cdf_table;
+    const float* x_table;
+    const float* target_logpdf;    /* interleaved [n, x0, lp0, ...] */
+    const float* proposal_logpdf;  /* interleaved */
+    int32_t  guard;
+} orc_mcmc_args;
+
+static float mcmc_sample_q(const orc_mcmc_args* a, orc_bm_state* bm, uint32_t idx, uint32_t iter) {
+    if (a->proposal_type == ORC_DIST_NORMAL)
+        return orc_sample_normal(bm, a->seed, idx, iter, a->param1, a->param2, a->guard);
+    float rng = orc_random_uniform(a->seed, idx, iter);
+    if (a->proposal_type == ORC_DIST_UNIFORM) {
+        if (a->guard && rng >= 1.0f) rng = 0x1.fffffep-1f;
+        return orc_sample_uniform(rng, a->param1, a->param2);
+    }
+    if (a->proposal_type == ORC_DIST_EXPONENTIAL) return orc_sample_exponential(rng, a->param1);
+    return orc_sample_from_cdf_table(rng, a->table_size, a->cdf_table, a->x_table);
+}
+
+/* out_ref[k]: the reference's f32 result. out_sum64[k]: f64 sums over all padded chains and sampling
+ * steps; out_sum64[K] = accepted steps (burn-in included). trace (optional): [chains_to_trace][n_steps]
+ * chain states after each sampling step, for evaluating arbitrary functions in numpy. */
+int orc_mcmc(const orc_mcmc_args* a, const orc_fn* fns, int K, float* out_ref, double* out_sum64,
+             uint64_t* n_eff, float* trace, uint32_t chains_to_trace) {
+    uint32_t cfg[4];
+    orc_mcmc_dispatch_config(a->n_chains, a->target_threads, cfg);
+    const uint32_t T = cfg[3];
+    if (n_eff) *n_eff = (uint64_t)T * (uint64_t)a->n_steps;
+    float* out = (float*)malloc((size_t)T * K * sizeof(float));
+    double* s64 = (double*)calloc((size_t)T * (K + 1), sizeof(double));
+    if (!out || !s64) { free(out); free(s64); return -1; }
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < (int64_t)T; ++t) {
+        uint32_t idx = (uint32_t)t;
+        orc_bm_state bm = {0, 0.0f};
+        float current_x = mcmc_sample_q(a, &bm, idx, 0u);                       /* shader_gen.rs:445-463 */
+        float current_log_p = orc_table_lookup(a->target_logpdf, current_x, -100.0f);
+        uint64_t accepted = 0;
+        float acc[64];
+        double acc64[64];
+        for (int k = 0; k < K; ++k) { acc[k] = 0.0f; acc64[k] = 0.0; }
+        uint32_t total = a->n_burnin + a->n_steps;
+        for (uint32_t it = 1u; it <= total; ++it) {                              /* burn-in: i+1 ; sampling: i+n_burnin+1 */
+            float proposal_x = mcmc_sample_q(a, &bm, idx, it + 1000000u);       /* shader_gen.rs:477-489 */
+            float proposal_log_p_target = orc_table_lookup(a->target_logpdf, proposal_x, -100.0f);
+            float proposal_log_q = orc_table_lookup(a->proposal_logpdf, proposal_x, -100.0f);
+            float current_log_q = orc_table_lookup(a->proposal_logpdf, current_x, -100.0f);
+            float log_alpha = proposal_log_p_target + current_log_q - current_log_p - proposal_log_q;
+            float u = orc_random_uniform(a->seed + 999999u, idx, it);            /* shader_gen.rs:529 */
+            if (logf(u) < log_alpha) {
+                current_x = proposal_x;
+                current_log_p = proposal_log_p_target;
+                ++accepted;
+            }
+            if (it > a->n_burnin) {
+                for (int k = 0; k < K; ++k) {
+                    float f = eval_fn(&fns[k], current_x);
+                    acc[k] += f;
+                    acc64[k] += (double)f;
+                }
+                if (trace && idx < chains_to_trace) trace[(size_t)idx * a->n_steps + (it - a->n_burnin - 1u)] = current_x;
+            }
+        }
+        for (int k = 0; k < K; ++k) {
+            out[(size_t)idx * K + k] = acc[k] / (float)a->n_steps;              /* shader_gen.rs:576 */
+            s64[(size_t)idx * (K + 1) + k] = acc64[k];
+        }
+        s64[(size_t)idx * (K + 1) + K] = (double)accepted;
+    }
+    for (int k = 0; k <= K; ++k) {
+        float sum = 0.0f;
+        double sum64 = 0.0;
+        for (uint32_t t = 0; t < T; ++t) {
+            if (k < K) sum += out[(size_t)t * K + k];
+            sum64 += s64[(size_t)t * (K + 1) + k];
+        }
+        if (k < K && out_ref) out_ref[k] = sum / (float)T;                       /* lib.rs:420-428 */
+        if (out_sum64) out_sum64[k] = sum64;
+    }
+    free(out); free(s64);
+    return 0;
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

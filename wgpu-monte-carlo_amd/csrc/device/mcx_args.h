@@ -1,0 +1,67 @@
+// mcx_args.h -- kernel argument blocks shared by the host runtime (mcx_runtime.cpp) and the
+// device kernels (mcx_kernels.hpp). Plain C layout, passed to the kernels by value.
+//
+// They replace the reference's uniform buffers IntegrationParams / McmcParams /
+// DistributionParamsBuffer (src/engine.rs:7-37) and its storage-buffer bindings
+// (src/engine.rs:334-390, 688-717, 1038-1136).
+#pragma once
+
+#ifdef __HIPCC_RTC__
+typedef unsigned int       mcx_u32;
+typedef unsigned long long mcx_u64;
+#else
+#include <stdint.h>
+typedef uint32_t mcx_u32;
+typedef uint64_t mcx_u64;
+#endif
+
+// One lookup table resident in HBM: n interleaved {key,value} float pairs.
+typedef struct McxTableDesc {
+    const float* kv;        // device pointer, 2*n floats ({cdf,x} or {x,pdf})
+    const mcx_u32* guide;   // device pointer, (1<<guide_bits)+1 entries, or null
+    mcx_u32 n;
+    mcx_u32 guide_bits;
+    float   inv_dk;         // (n-1)/(key[n-1]-key[0]) if the keys form a uniform grid, else 0
+    mcx_u32 _pad;
+} McxTableDesc;
+
+// K1 / K2: plain and importance-sampling integration.
+//
+// Logical grid (reference): idx in [0,T), i in [0,L). A launch covers idx in
+// [idx_begin, idx_begin+idx_count) x units in [unit_begin, unit_end), where a unit is one loop
+// iteration i (uniform / exponential / custom) or one Box-Muller pair j <-> iterations (2j, 2j+1)
+// (normal). Physical thread g handles logical index idx_begin + g % idx_count and the chunk
+// g / idx_count of `units_per_chunk` consecutive units.
+typedef struct McxIntegrateArgs {
+    mcx_u32 seed;
+    mcx_u32 idx_begin;
+    mcx_u32 idx_count;
+    mcx_u32 unit_begin;
+    mcx_u32 unit_end;
+    mcx_u32 units_per_chunk;
+    mcx_u32 n_chunks;
+    mcx_u32 loops_per_thread;   // L: a normal pair's second half is used only if 2j+1 < L
+    float   param1;             // min / mean / lambda
+    float   param2;             // max / std
+    mcx_u32 _pad0, _pad1;
+    McxTableDesc cdf;           // custom sampling distribution  {cdf, x}
+    McxTableDesc target_pdf;    // IS: target  {x, pdf}   (n == 0: analytic mcx_pdf_p)
+    McxTableDesc proposal_pdf;  // IS: proposal {x, pdf}  (n == 0: analytic mcx_pdf_q)
+    double* partials;           // [K][gridDim.x] per-workgroup partial sums
+} McxIntegrateArgs;
+
+// K3: independent-proposal Metropolis-Hastings, one chain per logical thread.
+typedef struct McxMcmcArgs {
+    mcx_u32 seed;
+    mcx_u32 chain_begin;        // first logical chain index of this launch
+    mcx_u32 chain_count;        // chains in this launch
+    mcx_u32 n_steps;
+    mcx_u32 n_burnin;
+    mcx_u32 _pad0;
+    float   param1;             // proposal min / mean / lambda
+    float   param2;             // proposal max / std
+    McxTableDesc cdf;           // custom proposal sampling {cdf, x}
+    McxTableDesc target_logpdf;   // {x, log p}
+    McxTableDesc proposal_logpdf; // {x, log q}
+    double* partials;           // [K+1][gridDim.x]; row K = accepted-step count
+} McxMcmcArgs;

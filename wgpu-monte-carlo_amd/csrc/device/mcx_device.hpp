@@ -1,0 +1,235 @@
+// mcx_device.hpp -- gfx950 (CDNA4, wave64) device library for the fused Monte-Carlo kernels.
+//
+// This text is compiled at run time by hiprtc (and ahead of time by hipcc for the build check);
+// it is prepended to the emitted user functions and followed by mcx_kernels.hpp.
+//
+// Semantics restated from the reference's WGSL device library (file:line are into /root/reference):
+//   pcg_hash / random_uniform          src/distribution.rs:62-73
+//   sample_uniform                     src/distribution.rs:80-82
+//   sample_normal_box_muller           src/distribution.rs:87-114
+//   sample_exponential                 src/distribution.rs:120-124
+//   sample_from_cdf_table              src/distribution.rs:128-158
+//   pdf_*_from_table / log_pdf_*       src/distribution.rs:181-223, 375-417
+// What is NOT kept: the WGSL text, the bind-group layout, the one-thread-per-logical-index mapping.
+// The u32 counter stream (seed + idx*7199369 + iter*15485863 -> PCG-RXS-M-XS) is bit-exact.
+#pragma once
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+#ifndef MCX_GUARD_ENDPOINTS
+#define MCX_GUARD_ENDPOINTS 1      // 1: u in (0,1] for log(), [0,1) for affine maps; 0: strict reference float(h)*2^-32
+#endif
+#ifndef MCX_PRECISE_SAMPLER
+#define MCX_PRECISE_SAMPLER 0      // 1: ocml logf/sinf/cosf in the samplers instead of v_log/v_sin/v_cos
+#endif
+
+#define MCX_PCG_MULT   747796405u
+#define MCX_PCG_INC    2891336453u
+#define MCX_PCG_OUTMUL 277803737u
+#define MCX_IDX_MULT   7199369u
+#define MCX_ITER_MULT  15485863u
+// The LCG stage of pcg_hash is affine in the counter, so stepping `iter` by d steps the LCG
+// state by d * MCX_STATE_STEP (mod 2^32): the first of the two multiplies of every hash is
+// strength-reduced to one add in the hot loops.
+#define MCX_STATE_STEP (MCX_ITER_MULT * MCX_PCG_MULT)
+
+#define MCX_DIST_UNIFORM     0
+#define MCX_DIST_NORMAL      1
+#define MCX_DIST_EXPONENTIAL 2
+#define MCX_DIST_CUSTOM      3
+
+#define MCX_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------
+// counter hash
+// ---------------------------------------------------------------------------------------------
+
+// LCG state of pcg_hash(seed + idx*7199369 + iter*15485863); all arithmetic wraps mod 2^32.
+MCX_DEV u32 mcx_state(u32 seed, u32 idx, u32 iter) {
+    u32 v = seed + idx * MCX_IDX_MULT + iter * MCX_ITER_MULT;
+    return v * MCX_PCG_MULT + MCX_PCG_INC;
+}
+
+// RXS-M-XS output permutation applied to an LCG state (distribution.rs:64-65).
+MCX_DEV u32 mcx_pcg_out(u32 state) {
+    u32 word = ((state >> ((state >> 28u) + 4u)) ^ state) * MCX_PCG_OUTMUL;
+    return (word >> 22u) ^ word;
+}
+
+// float(h) / 4294967295.0 in f32: the divisor literal rounds to 2^32, so this is an exact scale.
+// Closed interval: 0 iff h == 0, 1.0 iff h >= 0xFFFFFF80 (distribution.rs:72).
+MCX_DEV float mcx_u01_closed(u32 h) { return (float)h * 0x1.0p-32f; }
+
+// u for affine / table maps: [0,1) when guarded.
+MCX_DEV float mcx_u01(u32 h) {
+    float u = (float)h * 0x1.0p-32f;
+#if MCX_GUARD_ENDPOINTS
+    u = fminf(u, 0x1.fffffep-1f);
+#endif
+    return u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// samplers
+// ---------------------------------------------------------------------------------------------
+
+MCX_DEV float mcx_sample_uniform(float u, float lo, float hi) { return lo + u * (hi - lo); }
+
+MCX_DEV float mcx_native_ln(float x)   { return __builtin_amdgcn_logf(x) * 0x1.62e43p-1f; }   // v_log_f32 * ln2
+
+MCX_DEV float mcx_sample_exponential(float u, float lambda) {
+    float v = fmaxf(u, 1.0e-7f);
+#if MCX_PRECISE_SAMPLER
+    return -logf(v) / lambda;
+#else
+    return -mcx_native_ln(v) / lambda;
+#endif
+}
+
+// One Box-Muller pair from two hash outputs. z0 = r cos(2 pi u2), z1 = r sin(2 pi u2), r = sqrt(-2 ln u1).
+// v_sin_f32 / v_cos_f32 take their argument in revolutions, so u2 feeds them directly.
+MCX_DEV void mcx_box_muller(u32 h1, u32 h2, float& z0, float& z1) {
+    float f1 = (float)h1;
+#if MCX_GUARD_ENDPOINTS
+    f1 = fmaxf(f1, 0.5f);                         // h == 0 -> u1 = 2^-33 instead of log(0)
+#endif
+    float u2 = (float)h2 * 0x1.0p-32f;
+#if MCX_PRECISE_SAMPLER
+    float u1 = f1 * 0x1.0p-32f;
+    float r = sqrtf(-2.0f * logf(u1));
+    float theta = 6.283185307179586f * u2;
+    z0 = r * cosf(theta);
+    z1 = r * sinf(theta);
+#else
+    // -2 ln(f1 * 2^-32) = (32 - log2 f1) * 2 ln 2, never negative
+    float l2 = __builtin_amdgcn_logf(f1);
+    float r2 = fmaxf((32.0f - l2) * 0x1.62e43p+0f, 0.0f);
+    float r = __builtin_amdgcn_sqrtf(r2);
+    z0 = r * __builtin_amdgcn_cosf(u2);
+    z1 = r * __builtin_amdgcn_sinf(u2);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// tables
+// ---------------------------------------------------------------------------------------------
+// A table is n interleaved {key, value} pairs (float2). For CDF sampling key = cdf, value = x;
+// for PDF / log-PDF lookup key = x, value = pdf. The reference's buffers hold the same numbers as
+// [n, x0, v0, x1, v1, ...] (engine.rs:533-564) resp. two separate arrays (engine.rs:235-295).
+
+struct McxTable {
+    const float2* kv;     // LDS or global
+    u32   n;
+    float k0;             // kv[0].x
+    float inv_dk;         // (n-1)/(k[n-1]-k[0]) when the keys are a uniform grid, else 0
+    const u32* guide;     // CDF only: guide[b] = lower bound of b/G, (G+1) entries, or null
+    u32   guide_bits;     // G = 1 << guide_bits
+};
+
+// First index i in [0, n-1] with key[i] >= q, searching exactly like the reference's capped loop
+// (it never tests index n-1; `cap` = 12 for CDF sampling, 16 for PDF lookup).
+template <int CAP>
+MCX_DEV u32 mcx_lower_bound_capped(const float2* kv, u32 n, float q) {
+    u32 low = 0u, high = n - 1u;
+#pragma unroll 1
+    for (int j = 0; j < CAP; ++j) {
+        if (low >= high) break;
+        u32 mid = (low + high) >> 1;
+        if (kv[mid].x < q) low = mid + 1u; else high = mid;
+    }
+    return low;
+}
+
+MCX_DEV float mcx_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
+// sample_from_cdf_table (distribution.rs:128-158). key = cdf, value = x.
+MCX_DEV float mcx_sample_cdf(const McxTable& tb, float u) {
+    u32 n = tb.n;
+    u32 low;
+    if (tb.guide != nullptr) {
+        // bucket of u, then a short search inside [guide[b], guide[b+1]]: same index as the full
+        // lower bound because the table is non-decreasing (checked on the host) and n <= 4096.
+        u32 G = 1u << tb.guide_bits;
+        u32 b = (u32)(u * (float)G);
+        b = b > G - 1u ? G - 1u : b;
+        u32 lo = tb.guide[b], hi = tb.guide[b + 1u];
+        while (lo < hi) {
+            u32 mid = (lo + hi) >> 1;
+            if (tb.kv[mid].x < u) lo = mid + 1u; else hi = mid;
+        }
+        low = lo;
+    } else {
+        low = mcx_lower_bound_capped<12>(tb.kv, n, u);
+    }
+    u32 il = (low > 1u ? low : 1u) - 1u;
+    u32 ih = low < n - 1u ? low : n - 1u;
+    float2 a = tb.kv[il], b2 = tb.kv[ih];
+    float dc = b2.x - a.x;
+    if (dc < 1.0e-10f) return a.y;
+    float t = (u - a.x) / dc;
+    return mcx_mix(a.y, b2.y, t);
+}
+
+// pdf_*_from_table / log_pdf_*_from_table (distribution.rs:181-223, 375-417). key = x, value = pdf.
+// `outside` is 0.0 for PDF tables and -100.0 for log-PDF tables.
+MCX_DEV float mcx_table_lookup(const McxTable& tb, float x, float outside) {
+    u32 n = tb.n;
+    const float2* kv = tb.kv;
+    float x_min = tb.k0, x_max = kv[n - 1u].x;
+    if ((x < x_min) || (x > x_max)) return outside;
+    u32 low;
+    float2 a, b;
+    bool have = false;
+    if (tb.inv_dk != 0.0f) {
+        // uniform grid: guess the cell, verify it; the verified cell is exactly the one the
+        // reference's search + clamp selects (key[low] < x <= key[low+1]).
+        int g = (int)((x - x_min) * tb.inv_dk);
+        g = g < 0 ? 0 : (g > (int)n - 2 ? (int)n - 2 : g);
+        a = kv[g]; b = kv[g + 1];
+        if (a.x < x && x <= b.x) { low = (u32)g; have = true; }
+        else if (g > 0 && kv[g - 1].x < x && x <= a.x) { low = (u32)g - 1u; b = a; a = kv[low]; have = true; }
+        else if (g + 2 < (int)n && b.x < x && x <= kv[g + 2].x) { low = (u32)g + 1u; a = b; b = kv[low + 1u]; have = true; }
+    }
+    if (!have) {
+        low = mcx_lower_bound_capped<16>(kv, n, x);
+        low = (low > 1u ? low : 1u) - 1u;
+        low = low < n - 2u ? low : n - 2u;
+        a = kv[low]; b = kv[low + 1u];
+    }
+    float dx = b.x - a.x;
+    if (dx < 1.0e-10f) return a.y;
+    float t = (x - a.x) / dx;
+    return mcx_mix(a.y, b.y, t);
+}
+
+// ---------------------------------------------------------------------------------------------
+// WGSL builtins the emitter may call (semantics: W3C WGSL; reference FUNC_MAP transpiler.py:82-112)
+// ---------------------------------------------------------------------------------------------
+MCX_DEV float mcx_sign(float x)  { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+MCX_DEV float mcx_fract(float x) { return x - floorf(x); }
+MCX_DEV float mcx_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+MCX_DEV float mcx_step(float edge, float x) { return x >= edge ? 1.0f : 0.0f; }
+MCX_DEV float mcx_smoothstep(float lo, float hi, float x) {
+    float t = mcx_clamp((x - lo) / (hi - lo), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+MCX_DEV float mcx_select(float f, float t, bool c) { return c ? t : f; }
+MCX_DEV float mcx_b2f(bool b) { return b ? 1.0f : 0.0f; }
+MCX_DEV float mcx_b2f(float v) { return v; }
+MCX_DEV float mcx_b2f(int v) { return (float)v; }
+MCX_DEV float mcx_b2f(u32 v) { return (float)v; }
+
+// ---------------------------------------------------------------------------------------------
+// wave64 / workgroup reductions (fixed order => bit-reproducible for a fixed launch geometry)
+// ---------------------------------------------------------------------------------------------
+MCX_DEV double mcx_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+MCX_DEV u32 mcx_wave_sum_u32(u32 v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}

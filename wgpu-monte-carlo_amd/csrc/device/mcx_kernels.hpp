@@ -1,0 +1,357 @@
+// mcx_kernels.hpp -- the fused Monte-Carlo kernels for gfx950 (wave64, 256 CUs).
+//
+// Translation unit layout (assembled by mcx_runtime.cpp, compiled by hiprtc):
+//     #define MCX_K .. / MCX_DIST .. / MCX_BLOCK .. / MCX_WEIGHT .. / MCX_P_TABLE .. / MCX_Q_TABLE ..
+//     mcx_args.h, mcx_device.hpp
+//     <emitted user functions: user_func_0 .. user_func_{K-1}, optional mcx_pdf_p / mcx_pdf_q>
+//     <generated mcx_eval_all>
+//     mcx_kernels.hpp  (this file)
+//
+// Reference kernels these replace (file:line into /root/reference):
+//   K1 integrate             src/shader_gen.rs:58-118   (loop :105-112, epilogue :293-303)
+//   K2 integrate + PDF tables src/shader_gen.rs:149-213 (+ IS wrapper text python/wgpu_montecarlo/__init__.py:893-899, 968-974)
+//   K3 mcmc                  src/shader_gen.rs:347-429, step :511-537, epilogue :574-579
+//   host mean over threads   src/lib.rs:129-138
+//
+// Design differences (MI355X-first):
+//   * logical (idx, i) sample grid is decoupled from physical threads: each logical thread's loop
+//     is cut into chunks so that >= 16 waves/CU are resident whatever T is; the multiset of samples
+//     is unchanged, only the summation order differs.
+//   * per-thread sums go f32 registers -> f64 registers every MCX_FLUSH units -> wave64 xor-shuffle
+//     -> LDS across waves -> one coalesced row of `partials[k][workgroup]`; a second tiny kernel
+//     folds the rows in a fixed order. No [T][K] output buffer, no host-side reduction.
+//   * lookup tables are staged once per workgroup into LDS as interleaved float2.
+//   * the importance weight p/q is computed once per sample, not once per function.
+#pragma once
+
+#ifndef MCX_K
+#error "MCX_K must be defined"
+#endif
+#ifndef MCX_DIST
+#error "MCX_DIST must be defined"
+#endif
+#ifndef MCX_BLOCK
+#define MCX_BLOCK 256
+#endif
+#ifndef MCX_WEIGHT
+#define MCX_WEIGHT 0
+#endif
+#ifndef MCX_P_TABLE
+#define MCX_P_TABLE 0
+#endif
+#ifndef MCX_Q_TABLE
+#define MCX_Q_TABLE 0
+#endif
+#ifndef MCX_TABLES_LDS
+#define MCX_TABLES_LDS 1
+#endif
+#ifndef MCX_FLUSH
+#define MCX_FLUSH 128            // units accumulated in f32 before folding into the f64 sums
+#endif
+
+#define MCX_WAVES (MCX_BLOCK / 64)
+
+extern __shared__ __attribute__((aligned(16))) unsigned char mcx_lds_raw[];
+
+// Copy one table into LDS at byte offset `off` (advanced), or leave it in HBM.
+MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
+    McxTable t;
+    t.n = d.n;
+    t.inv_dk = d.inv_dk;
+    t.guide_bits = d.guide_bits;
+    t.guide = nullptr;
+    t.kv = nullptr;
+    t.k0 = 0.0f;
+    if (d.n == 0u) return t;
+#if MCX_TABLES_LDS
+    float2* dst = (float2*)(mcx_lds_raw + off);
+    const float2* src = (const float2*)d.kv;
+    for (u32 i = threadIdx.x; i < d.n; i += MCX_BLOCK) dst[i] = src[i];
+    off += d.n * 8u;
+    t.kv = dst;
+    if (d.guide != nullptr) {
+        u32* gdst = (u32*)(mcx_lds_raw + off);
+        u32 gn = (1u << d.guide_bits) + 1u;
+        for (u32 i = threadIdx.x; i < gn; i += MCX_BLOCK) gdst[i] = d.guide[i];
+        off += ((gn + 1u) & ~1u) * 4u;
+        t.guide = gdst;
+    }
+#else
+    t.kv = (const float2*)d.kv;
+    t.guide = d.guide;
+#endif
+    t.k0 = d.kv[0];
+    return t;
+}
+
+// Fold the per-thread f64 sums of a workgroup and store row k at partials[k*gridDim.x + blockIdx.x].
+template <int N>
+MCX_DEV void mcx_block_reduce_store(double (&v)[N], double* partials) {
+    __shared__ double red[MCX_WAVES][N];
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double s = mcx_wave_sum(v[k]);
+        if (lane == 0u) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < (u32)N) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < MCX_WAVES; ++w) s += red[w][threadIdx.x];
+        partials[(u64)threadIdx.x * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+// =============================================================================================
+// K1 / K2: fused sample + (weight) + K evaluations + reduction
+// =============================================================================================
+struct McxIsTables { McxTable p, q; };
+
+MCX_DEV void mcx_accumulate(float x, const McxIsTables& tb, float (&acc)[MCX_K]) {
+#if MCX_WEIGHT
+#if MCX_P_TABLE
+    float p = mcx_table_lookup(tb.p, x, 0.0f);
+#else
+    float p = mcx_b2f(mcx_pdf_p(x));
+#endif
+#if MCX_Q_TABLE
+    float q = mcx_table_lookup(tb.q, x, 0.0f);
+#else
+    float q = mcx_b2f(mcx_pdf_q(x));
+#endif
+    mcx_eval_all(x, p / q, acc);
+#else
+    mcx_eval_all(x, 1.0f, acc);
+#endif
+}
+
+extern "C" __global__ void __launch_bounds__(MCX_BLOCK)
+mcx_integrate_kernel(McxIntegrateArgs a) {
+    u32 lds_off = 0u;
+    McxTable cdf_tb = mcx_stage_table(a.cdf, lds_off);
+    McxIsTables is_tb;
+    is_tb.p = mcx_stage_table(a.target_pdf, lds_off);
+    is_tb.q = mcx_stage_table(a.proposal_pdf, lds_off);
+    (void)cdf_tb;
+    __syncthreads();
+
+    const u32 g = blockIdx.x * MCX_BLOCK + threadIdx.x;
+    const u32 total = a.idx_count * a.n_chunks;
+    const bool active = g < total;
+    const u32 chunk = active ? g / a.idx_count : 0u;
+    const u32 idx = a.idx_begin + (active ? g - chunk * a.idx_count : 0u);
+    u32 u0 = a.unit_begin + chunk * a.units_per_chunk;
+    u32 u1 = u0 + a.units_per_chunk;
+    u1 = u1 < a.unit_end ? u1 : a.unit_end;
+    if (!active) { u0 = 0u; u1 = 0u; }
+
+    double sum[MCX_K];
+#pragma unroll
+    for (int k = 0; k < MCX_K; ++k) sum[k] = 0.0;
+
+#if MCX_DIST == MCX_DIST_NORMAL
+    // unit = Box-Muller pair j: iterations (2j, 2j+1), counters (4j, 4j+1) (distribution.rs:97-98)
+    const u32 full_pairs = a.loops_per_thread >> 1;          // pairs whose second half is used
+    const u32 e_full = u1 < full_pairs ? u1 : full_pairs;
+    u32 st = mcx_state(a.seed, idx, 4u * u0);
+    u32 j = u0;
+    while (j < e_full) {
+        u32 blk_end = j + MCX_FLUSH;
+        blk_end = blk_end < e_full ? blk_end : e_full;
+        float acc[MCX_K];
+#pragma unroll
+        for (int k = 0; k < MCX_K; ++k) acc[k] = 0.0f;
+        for (; j < blk_end; ++j) {
+            u32 h1 = mcx_pcg_out(st);
+            u32 h2 = mcx_pcg_out(st + MCX_STATE_STEP);
+            st += 4u * MCX_STATE_STEP;
+            float z0, z1;
+            mcx_box_muller(h1, h2, z0, z1);
+            mcx_accumulate(a.param1 + a.param2 * z0, is_tb, acc);
+            mcx_accumulate(a.param1 + a.param2 * z1, is_tb, acc);
+        }
+#pragma unroll
+        for (int k = 0; k < MCX_K; ++k) sum[k] += (double)acc[k];
+    }
+    if (active && u1 > full_pairs) {
+        // L odd: the last pair contributes z0 only, z1 is discarded (shader_gen.rs:105-112)
+        st = mcx_state(a.seed, idx, 4u * full_pairs);
+        u32 h1 = mcx_pcg_out(st);
+        u32 h2 = mcx_pcg_out(st + MCX_STATE_STEP);
+        float z0, z1;
+        mcx_box_muller(h1, h2, z0, z1);
+        float acc[MCX_K];
+#pragma unroll
+        for (int k = 0; k < MCX_K; ++k) acc[k] = 0.0f;
+        mcx_accumulate(a.param1 + a.param2 * z0, is_tb, acc);
+#pragma unroll
+        for (int k = 0; k < MCX_K; ++k) sum[k] += (double)acc[k];
+    }
+#else
+    // unit = iteration i, counter i (distribution.rs:333)
+    u32 st = mcx_state(a.seed, idx, u0);
+    u32 i = u0;
+    while (i < u1) {
+        u32 blk_end = i + MCX_FLUSH;
+        blk_end = blk_end < u1 ? blk_end : u1;
+        float acc[MCX_K];
+#pragma unroll
+        for (int k = 0; k < MCX_K; ++k) acc[k] = 0.0f;
+#pragma unroll 2
+        for (; i < blk_end; ++i) {
+            u32 h = mcx_pcg_out(st);
+            st += MCX_STATE_STEP;
+#if MCX_DIST == MCX_DIST_UNIFORM
+            float x = mcx_sample_uniform(mcx_u01(h), a.param1, a.param2);
+#elif MCX_DIST == MCX_DIST_EXPONENTIAL
+            float x = mcx_sample_exponential(mcx_u01_closed(h), a.param1);
+#else
+            float x = mcx_sample_cdf(cdf_tb, mcx_u01_closed(h));
+#endif
+            mcx_accumulate(x, is_tb, acc);
+        }
+#pragma unroll
+        for (int k = 0; k < MCX_K; ++k) sum[k] += (double)acc[k];
+    }
+#endif
+
+    mcx_block_reduce_store<MCX_K>(sum, a.partials);
+}
+
+// =============================================================================================
+// K3: independent-proposal Metropolis-Hastings, one chain per thread
+// =============================================================================================
+#ifndef MCX_PROP_ITER_OFFSET
+#define MCX_PROP_ITER_OFFSET 1000000u      // shader_gen.rs:477-489
+#endif
+#ifndef MCX_ACCEPT_SEED_OFFSET
+#define MCX_ACCEPT_SEED_OFFSET 999999u     // shader_gen.rs:529
+#endif
+
+extern "C" __global__ void __launch_bounds__(MCX_BLOCK)
+mcx_mcmc_kernel(McxMcmcArgs a) {
+    u32 lds_off = 0u;
+    McxTable cdf_tb = mcx_stage_table(a.cdf, lds_off);
+    McxTable lp_tb = mcx_stage_table(a.target_logpdf, lds_off);
+    McxTable lq_tb = mcx_stage_table(a.proposal_logpdf, lds_off);
+    (void)cdf_tb;
+    __syncthreads();
+
+    const u32 g = blockIdx.x * MCX_BLOCK + threadIdx.x;
+    const bool active = g < a.chain_count;
+    const u32 idx = a.chain_begin + (active ? g : 0u);
+    const u32 total_steps = active ? a.n_burnin + a.n_steps : 0u;
+
+    double sum[MCX_K + 1];
+#pragma unroll
+    for (int k = 0; k <= MCX_K; ++k) sum[k] = 0.0;
+    float acc[MCX_K];
+#pragma unroll
+    for (int k = 0; k < MCX_K; ++k) acc[k] = 0.0f;
+    u32 n_accept = 0u;
+    u32 since_flush = 0u;
+
+    // ---- initial state ~ proposal, counter iter = 0 (shader_gen.rs:445-463) ----
+    float cur_x;
+#if MCX_DIST == MCX_DIST_NORMAL
+    float z_cached;
+    {
+        u32 s0 = mcx_state(a.seed, idx, 0u);
+        float z0;
+        mcx_box_muller(mcx_pcg_out(s0), mcx_pcg_out(s0 + MCX_STATE_STEP), z0, z_cached);
+        cur_x = a.param1 + a.param2 * z0;       // z1 stays cached for step it = 1
+    }
+    // proposal state for even `it`: counters 2*(it+OFFSET), 2*(it+OFFSET)+1
+    u32 st_prop = mcx_state(a.seed, idx, 2u * (2u + MCX_PROP_ITER_OFFSET));
+#else
+    {
+        u32 h = mcx_pcg_out(mcx_state(a.seed, idx, 0u));
+#if MCX_DIST == MCX_DIST_UNIFORM
+        cur_x = mcx_sample_uniform(mcx_u01(h), a.param1, a.param2);
+#elif MCX_DIST == MCX_DIST_EXPONENTIAL
+        cur_x = mcx_sample_exponential(mcx_u01_closed(h), a.param1);
+#else
+        cur_x = mcx_sample_cdf(cdf_tb, mcx_u01_closed(h));
+#endif
+    }
+    u32 st_prop = mcx_state(a.seed, idx, 1u + MCX_PROP_ITER_OFFSET);
+#endif
+    float cur_lp = mcx_table_lookup(lp_tb, cur_x, -100.0f);
+    float cur_lq = mcx_table_lookup(lq_tb, cur_x, -100.0f);   // pure function of cur_x: cached
+    u32 st_acc = mcx_state(a.seed + MCX_ACCEPT_SEED_OFFSET, idx, 1u);
+
+    for (u32 it = 1u; it <= total_steps; ++it) {
+        // ---- proposal x' ~ q with counter it + OFFSET ----
+        float prop_x;
+#if MCX_DIST == MCX_DIST_NORMAL
+        if (it & 1u) {
+            prop_x = a.param1 + a.param2 * z_cached;           // second half of the previous pair
+        } else {
+            float z0;
+            mcx_box_muller(mcx_pcg_out(st_prop), mcx_pcg_out(st_prop + MCX_STATE_STEP), z0, z_cached);
+            st_prop += 4u * MCX_STATE_STEP;                    // next even `it` is it + 2
+            prop_x = a.param1 + a.param2 * z0;
+        }
+#else
+        {
+            u32 h = mcx_pcg_out(st_prop);
+            st_prop += MCX_STATE_STEP;
+#if MCX_DIST == MCX_DIST_UNIFORM
+            prop_x = mcx_sample_uniform(mcx_u01(h), a.param1, a.param2);
+#elif MCX_DIST == MCX_DIST_EXPONENTIAL
+            prop_x = mcx_sample_exponential(mcx_u01_closed(h), a.param1);
+#else
+            prop_x = mcx_sample_cdf(cdf_tb, mcx_u01_closed(h));
+#endif
+        }
+#endif
+        // ---- MH ratio (shader_gen.rs:518-526) ----
+        float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
+        float prop_lq = mcx_table_lookup(lq_tb, prop_x, -100.0f);
+        float log_alpha = prop_lp + cur_lq - cur_lp - prop_lq;
+        // ---- accept: log(U(seed+999999, idx, it)) < log_alpha (shader_gen.rs:529-534) ----
+        u32 ha = mcx_pcg_out(st_acc);
+        st_acc += MCX_STATE_STEP;
+#if MCX_PRECISE_SAMPLER
+        float ln_u = logf(mcx_u01_closed(ha));
+#else
+        float ln_u = (__builtin_amdgcn_logf((float)ha) - 32.0f) * 0x1.62e43p-1f;   // h = 0 -> -inf
+#endif
+        if (ln_u < log_alpha) {
+            cur_x = prop_x;
+            cur_lp = prop_lp;
+            cur_lq = prop_lq;
+            ++n_accept;
+        }
+        // ---- accumulate after every sampling step, accepted or not (shader_gen.rs:417-423) ----
+        if (it > a.n_burnin) {
+            mcx_eval_all(cur_x, 1.0f, acc);
+            if (++since_flush == 2u * MCX_FLUSH) {
+#pragma unroll
+                for (int k = 0; k < MCX_K; ++k) { sum[k] += (double)acc[k]; acc[k] = 0.0f; }
+                since_flush = 0u;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MCX_K; ++k) sum[k] += (double)acc[k];
+    sum[MCX_K] = (double)n_accept;
+
+    mcx_block_reduce_store<MCX_K + 1>(sum, a.partials);
+}
+
+// =============================================================================================
+// stage 2: fold partials[rows][n_blocks] -> out[rows] in a fixed order (one workgroup per row)
+// =============================================================================================
+extern "C" __global__ void __launch_bounds__(256)
+mcx_fold_kernel(const double* partials, u32 n_blocks, double* out) {
+    __shared__ double red[4];
+    const double* row = partials + (u64)blockIdx.x * n_blocks;
+    double s = 0.0;
+    for (u32 i = threadIdx.x; i < n_blocks; i += 256u) s += row[i];
+    s = mcx_wave_sum(s);
+    if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0u) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}

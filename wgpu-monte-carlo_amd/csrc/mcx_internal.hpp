@@ -1,0 +1,24 @@
+// mcx_internal.hpp -- declarations shared by mcx_plan.cpp and mcx_runtime.cpp
+#pragma once
+#include "../../include/mcx.h"
+
+#include <string>
+#include <vector>
+
+namespace mcx {
+
+// Record an error message for mcx_last_error() and return `code`.
+int fail(int code, const std::string& msg);
+
+struct LaunchPlan {
+    uint32_t units_per_chunk;
+    uint32_t n_chunks;
+    uint32_t n_blocks;      // 0: nothing to launch (empty shard)
+};
+
+LaunchPlan plan_integrate(const mcx_shard& s, uint32_t target_phys, uint32_t block);
+
+void analyse_table(int kind, const float* keys, uint32_t n, float* inv_dk, std::vector<uint32_t>* guide,
+                   uint32_t* guide_bits);
+
+}  // namespace mcx

@@ -1,0 +1,139 @@
+// mcx_plan.cpp -- pure host planning: logical dispatch geometry (bit-exact with the reference),
+// multi-GPU shard ranges, physical launch geometry, table analysis. No HIP calls in this file.
+//
+// Reference (file:line into /root/reference):
+//   calculate_dispatch_config        src/engine.rs:157-181
+//   calculate_mcmc_dispatch_config   src/engine.rs:821-832,  setup_mcmc chain padding :860-866
+#include "mcx_internal.hpp"
+
+#include <cmath>
+#include <cstring>
+
+extern "C" {
+
+int mcx_dispatch_config(uint64_t n_samples, int64_t target_threads, mcx_dispatch* out) {
+    if (!out) return mcx::fail(MCX_E_INVALID, "mcx_dispatch_config: out is null");
+    if (target_threads > 0xFFFFFFFFll) return mcx::fail(MCX_E_INVALID, "target_threads does not fit u32");
+    // engine.rs:164-168 -- u32 arithmetic (target + 255 may not wrap for sane inputs; keep u32 like the reference)
+    uint32_t target = target_threads > 0 ? (uint32_t)target_threads : 65536u;
+    const uint32_t wg = 256u;
+    uint32_t wgc = (target + wg - 1u) / wg;
+    uint32_t total = wgc * wg;
+    if (total == 0u) return mcx::fail(MCX_E_INVALID, "target_threads rounds to zero threads");
+    // engine.rs:172-173 -- u64 ceiling division, truncating cast to u32
+    uint32_t loops = (uint32_t)((n_samples + (uint64_t)total - 1ull) / (uint64_t)total);
+    out->workgroup_size = wg;
+    out->workgroup_count = wgc;
+    out->loops_per_thread = loops;
+    out->total_threads = total;
+    return MCX_OK;
+}
+
+int mcx_mcmc_dispatch_config(uint32_t n_chains, int64_t target_threads, mcx_dispatch* out) {
+    if (!out) return mcx::fail(MCX_E_INVALID, "mcx_mcmc_dispatch_config: out is null");
+    if (target_threads > 0xFFFFFFFFll) return mcx::fail(MCX_E_INVALID, "target_threads does not fit u32");
+    uint32_t chains = target_threads > 0 ? (uint32_t)target_threads : n_chains;   // engine.rs:860
+    const uint32_t wg = 256u;
+    uint32_t wgc = (chains + wg - 1u) / wg;                                       // engine.rs:823
+    out->workgroup_size = wg;
+    out->workgroup_count = wgc;
+    out->loops_per_thread = 1u;                                                   // engine.rs:829
+    out->total_threads = wgc * wg;
+    return MCX_OK;
+}
+
+int mcx_shard_integrate(const mcx_dispatch* d, int dist_type, uint32_t rank, uint32_t world, mcx_shard* out) {
+    if (!d || !out) return mcx::fail(MCX_E_INVALID, "mcx_shard_integrate: null argument");
+    if (world == 0u || rank >= world) return mcx::fail(MCX_E_INVALID, "mcx_shard_integrate: rank/world out of range");
+    const uint32_t L = d->loops_per_thread;
+    // units per logical thread: iterations, or Box-Muller pairs for the normal sampler
+    const uint64_t units = dist_type == MCX_DIST_NORMAL ? ((uint64_t)L + 1ull) / 2ull : (uint64_t)L;
+    if (units >= (uint64_t)world) {
+        // split the iteration axis: every rank sees every logical idx, a contiguous unit range
+        out->idx_begin = 0u;
+        out->idx_count = d->total_threads;
+        out->unit_begin = (uint32_t)(units * rank / world);
+        out->unit_end = (uint32_t)(units * (rank + 1ull) / world);
+    } else {
+        // fewer units than ranks: split the idx axis in whole reference workgroups of 256
+        const uint64_t wgc = d->workgroup_count;
+        uint32_t b0 = (uint32_t)(wgc * rank / world), b1 = (uint32_t)(wgc * (rank + 1ull) / world);
+        out->idx_begin = b0 * 256u;
+        out->idx_count = (b1 - b0) * 256u;
+        out->unit_begin = 0u;
+        out->unit_end = (uint32_t)units;
+    }
+    return MCX_OK;
+}
+
+int mcx_shard_chains(uint32_t total_chains, uint32_t rank, uint32_t world,
+                     uint32_t* chain_begin, uint32_t* chain_count) {
+    if (!chain_begin || !chain_count) return mcx::fail(MCX_E_INVALID, "mcx_shard_chains: null argument");
+    if (world == 0u || rank >= world) return mcx::fail(MCX_E_INVALID, "mcx_shard_chains: rank/world out of range");
+    if (total_chains % 256u) return mcx::fail(MCX_E_INVALID, "mcx_shard_chains: total_chains must be a multiple of 256");
+    const uint64_t wgc = total_chains / 256u;
+    uint32_t b0 = (uint32_t)(wgc * rank / world), b1 = (uint32_t)(wgc * (rank + 1ull) / world);
+    *chain_begin = b0 * 256u;
+    *chain_count = (b1 - b0) * 256u;
+    return MCX_OK;
+}
+
+}  // extern "C"
+
+namespace mcx {
+
+// Physical geometry for K1/K2: cut each logical thread's unit range into n_chunks so that about
+// `target_phys` physical threads exist (>= 16 waves per CU on 256 CUs), never more chunks than units.
+LaunchPlan plan_integrate(const mcx_shard& s, uint32_t target_phys, uint32_t block) {
+    LaunchPlan p{};
+    const uint64_t units = s.unit_end > s.unit_begin ? (uint64_t)(s.unit_end - s.unit_begin) : 0ull;
+    if (units == 0ull || s.idx_count == 0u) return p;    // empty shard
+    uint64_t want = ((uint64_t)target_phys + s.idx_count - 1ull) / s.idx_count;
+    if (want < 1ull) want = 1ull;
+    if (want > units) want = units;
+    uint64_t upc = (units + want - 1ull) / want;
+    uint64_t n_chunks = (units + upc - 1ull) / upc;
+    p.units_per_chunk = (uint32_t)upc;
+    p.n_chunks = (uint32_t)n_chunks;
+    uint64_t threads = (uint64_t)s.idx_count * n_chunks;
+    p.n_blocks = (uint32_t)((threads + block - 1ull) / block);
+    return p;
+}
+
+// Analyse a table on the host: uniform-grid scale for {x, value} tables, guide table for CDFs.
+void analyse_table(int kind, const float* keys, uint32_t n, float* inv_dk, std::vector<uint32_t>* guide,
+                   uint32_t* guide_bits) {
+    *inv_dk = 0.0f;
+    *guide_bits = 0u;
+    guide->clear();
+    if (n < 2u) return;
+    if (kind == MCX_TABLE_PDF || kind == MCX_TABLE_LOGPDF) {
+        const double k0 = keys[0], span = (double)keys[n - 1u] - k0;
+        if (!(span > 0.0) || !std::isfinite(span)) return;
+        const double dk = span / (double)(n - 1u);
+        bool uniform = true;
+        for (uint32_t i = 0; i < n && uniform; ++i)
+            uniform = std::fabs((double)keys[i] - (k0 + dk * (double)i)) <= 0.25 * dk;
+        if (uniform) *inv_dk = (float)(1.0 / dk);
+        return;
+    }
+    // CDF: the guide is only valid where the reference's 12-step search is an exact lower bound
+    // (n <= 4096, distribution.rs:133) and the keys are non-decreasing.
+    if (n > 4096u) return;
+    for (uint32_t i = 1; i < n; ++i)
+        if (!(keys[i] >= keys[i - 1u])) return;
+    uint32_t bits = 0u;
+    while ((1u << bits) < n) ++bits;
+    const uint32_t G = 1u << bits;
+    guide->resize(G + 1u);
+    uint32_t i = 0u;
+    for (uint32_t b = 0; b <= G; ++b) {
+        const float q = (float)b / (float)G;
+        // first i in [0, n-2] with key[i] >= q, else n-1 (the reference never tests index n-1)
+        while (i < n - 1u && keys[i] < q) ++i;
+        (*guide)[b] = i;
+    }
+    *guide_bits = bits;
+}
+
+}  // namespace mcx
