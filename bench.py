@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: samples/sec of the fused K=4 integrate on N(0,1) (BASELINE config C2).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--samples-per-gpu S]
+
+One step = one pass of the hot path: integrate([x, x**2, x**3, x**4], Normal(0,1), n_samples = S*N)
+(fused RNG + Box-Muller + 4 evaluations + two-stage f64 reduction; for N > 1 each rank runs its shard
+of the SAME logical sample grid and the K partial sums are combined by one RCCL all-reduce). Weak
+scaling: S = 1e9 samples per GPU per step. Inputs (four scalars) are kernel arguments; nothing is
+staged from the host inside the timed region. Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for _p in (ROOT / "wgpu-monte-carlo_amd", ROOT):
+    if str(_p) not in sys.path:
+        sys.path.insert(0, str(_p))
+
+K = 4
+TRUTH = (0.0, 1.0, 0.0, 3.0)
+# variance of x^k under N(0,1): E[x^2k] - E[x^k]^2 = 1, 2, 15, 96
+SIGMA = (1.0, 2.0 ** 0.5, 15.0 ** 0.5, 96.0 ** 0.5)
+
+# Algorithmic VALU cost of one sample of this workload, in lane-op equivalents (DESIGN.md "Roofline"):
+# per Box-Muller pair 25 plain ops + 2 integer multiplies (x4) + 4 transcendentals (x2), per sample
+# 3 multiplies + 4 adds  ->  (25 + 8 + 8) / 2 + 7 = 27.5
+OPS_PER_SAMPLE = 27.5
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9      # 7.86e13: CUs x SIMDs x lanes x clock (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0
+
+
+def moment_functions():
+    f1 = lambda x: x
+    f2 = lambda x: x**2
+    f3 = lambda x: x**3
+    f4 = lambda x: x**4
+    return [f1, f2, f3, f4]
+
+
+def prewarm_cache():
+    """hiprtc-compile the bench / smoke modules into the in-tree code-object cache (needs no GPU)."""
+    from wgpu_montecarlo import runtime as rt
+    from wgpu_montecarlo.api import functions_to_hip
+
+    src = functions_to_hip(moment_functions())
+    for dist in (rt.DIST_UNIFORM, rt.DIST_NORMAL, rt.DIST_EXPONENTIAL, rt.DIST_CUSTOM):
+        rt.precompile(src, rt.make_desc(rt.KIND_INTEGRATE, K, dist))
+
+
+def cpu_baseline(n_samples: int):
+    """Time the CPU oracle (plain-C restatement of the reference kernel, OpenMP over the logical
+    thread index) on a bounded sample of the same workload."""
+    import oracle
+
+    fns = [(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2), (oracle.FN_POW, 3), (oracle.FN_POW, 4)]
+    oracle.integrate(fns, oracle.NORMAL, 0.0, 1.0, n_samples=1_000_000, seed=1)     # warm up threads
+    t0 = time.perf_counter()
+    res = oracle.integrate(fns, oracle.NORMAL, 0.0, 1.0, n_samples=n_samples, seed=42)
+    dt = time.perf_counter() - t0
+    return dict(value=res["n_eff"] / dt, unit="samples/s", cores=oracle.num_threads(), kind="port",
+                sample=f"K=4 moments on N(0,1), n={n_samples:.0e} (N_eff {res['n_eff']}) of the 1e9-per-GPU workload, "
+                       f"oracle/mcx_oracle.c with OpenMP, {dt:.2f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--samples-per-gpu", type=float, default=1e9)
+    ap.add_argument("--cpu-samples", type=float, default=2e8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--target-phys", type=int, default=0, help="physical threads per launch (tuning)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+
+    integ = MonteCarloIntegrator(device=local_rank)
+    if args.target_phys:
+        integ._engine.set_target_threads(args.target_phys)
+    prepared = integ.prepare_integrate(moment_functions(), Distribution.normal(0.0, 1.0))
+    n_total = int(args.samples_per_gpu) * world
+    out = torch.zeros(args.warmup + args.steps + 1, K, dtype=torch.float64, device=device)
+
+    def step(i):
+        return prepared.launch(n_total, 42 + i, out[i])
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        n_eff = step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        n_eff = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # accuracy of every timed step (sums over all ranks are already in `out`)
+    means = (out[args.warmup:args.warmup + args.steps] / float(n_eff)).cpu().numpy()
+    abs_err = np.abs(means - np.array(TRUTH))
+    three_sigma = 3.0 * np.array(SIGMA) / np.sqrt(float(n_eff))
+    worst_ratio = float((abs_err / three_sigma).max())
+
+    # dominant kernel: HIP-event duration on the stream it runs on, one launch at a time
+    durations = []
+    for j in range(10):
+        step(args.warmup + args.steps)
+        durations.append(integ._engine.last_kernel_ms())
+    kernel_ms = float(np.mean(durations))
+    launch = integ._engine.last_launch()
+    samples_per_launch = n_eff / world
+    valu_achieved = samples_per_launch * OPS_PER_SAMPLE / (kernel_ms * 1e-3)
+    hbm_bytes = launch["n_blocks"] * K * 8.0
+    hbm_gbps = hbm_bytes / (kernel_ms * 1e-3) / 1e9
+
+    # blocking Python-API latency for the same call (includes emission + launch + D2H of K doubles)
+    t1 = time.perf_counter()
+    res = integ.integrate(moment_functions(), Distribution.normal(0.0, 1.0), n_samples=n_total, seed=42)
+    api_ms = (time.perf_counter() - t1) * 1e3
+    fence()
+
+    if rank == 0:
+        value = n_total * args.steps / elapsed
+        line = {
+            "metric": "samples/sec (whole node), K=4 fused functions on N(0,1)",
+            "value": value,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "integrate([x, x**2, x**3, x**4], Normal(0,1)), n_samples=1e9 per GPU per step "
+                            "(BASELINE configs[1]); logical grid T=65536",
+                "n_samples_per_step": n_total,
+                "n_eff_per_step": int(n_eff),
+                "parallelism": f"sample-grid shards x{world}, one RCCL sum all-reduce of {K} f64" if world > 1 else "single GPU",
+                "accumulate": "f32 registers per 128 pairs -> f64",
+            },
+            "abs_err_vs_truth": abs_err.max(axis=0).tolist(),
+            "three_sigma": three_sigma.tolist(),
+            "worst_err_over_3sigma": worst_ratio,
+            "per_gpu_samples_per_s": value / world,
+            "api_call_ms": api_ms,
+            "api_values": res.values.tolist(),
+            "roofline": {
+                "bound": "valu",
+                "achieved": valu_achieved / 1e12,
+                "peak": VALU_PEAK_LANEOPS / 1e12,
+                "unit": "Tlane-op/s",
+                "frac": valu_achieved / VALU_PEAK_LANEOPS,
+                "traffic": None,
+                "kernel": "mcx_integrate_kernel",
+                "kernel_ms": kernel_ms,
+                "ops_per_sample": OPS_PER_SAMPLE,
+                "launch": launch,
+                "hbm": {"bound": "hbm", "achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": hbm_gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": hbm_bytes,
+                        "note": "the fused kernel writes K*8 B per workgroup and reads nothing: HBM is not the bound"},
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(int(args.cpu_samples))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,305 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical counter streams.
+
+Tolerances (stated per test): the integer side -- T, L, N_eff, padded chain counts -- is bit-exact. The
+floating-point side is compared with the oracle's f64 sums of the same f32 samples; the remaining
+difference comes from (a) v_log/v_sin/v_cos/v_sqrt vs glibc logf/sinf/cosf/sqrtf in the samplers
+(<= a few ulp per sample), (b) x*x*.. vs powf, (c) p/q computed once vs f*p/q, (d) summation order.
+Observed |diff| is ~1e-7..1e-6 on O(1) means; the asserted bound is 2e-5 (absolute + relative), about
+100x below the Monte-Carlo 3-sigma at these sizes. math="precise" (ocml in the samplers) is held to 2e-6.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+MOMENTS = [lambda x: x, lambda x: x**2, lambda x: x**3, lambda x: x**4]
+ORC_MOMENTS = [(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2), (oracle.FN_POW, 3), (oracle.FN_POW, 4)]
+TOL = 2e-5
+
+
+def close(got, want, tol=TOL):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    err = np.abs(got - want)
+    ok = np.all(err <= tol + tol * np.abs(want))
+    return ok, f"got {got} want {want} |diff| {err}"
+
+
+def test_engine_reports_gfx950(integrator):
+    assert integrator._engine.device == 0
+
+
+@pytest.mark.parametrize("n_samples,target", [(1_000_000, None), (1_000, None), (3_000_000, 32768),
+                                             (1_114_112, None), (200_000, 1000)])
+def test_normal_moments_match_oracle(integrator, n_samples, target):
+    """K1, normal sampler: same samples as the oracle for several (T, L), incl. odd L and L = 1."""
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+
+    integ = integrator if target is None else MonteCarloIntegrator(target_threads=target)
+    res = integ.integrate(MOMENTS, Distribution.normal(0.5, 1.5), n_samples=n_samples, seed=1234)
+    ref = oracle.integrate(ORC_MOMENTS, oracle.NORMAL, 0.5, 1.5, n_samples=n_samples, seed=1234,
+                           target_threads=target, guard=1)
+    assert res.meta["n_eff"] == ref["n_eff"]
+    ok, msg = close(res.values, ref["sums"] / ref["n_eff"])
+    assert ok, msg
+    # and the reference's own f32 accumulation stays within its rounding noise of our f64 result
+    ok, msg = close(res.values, ref["ref"], tol=5e-4)
+    assert ok, msg
+
+
+def test_normal_precise_math_is_tighter():
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+
+    integ = MonteCarloIntegrator(math="precise")
+    res = integ.integrate(MOMENTS, Distribution.normal(0.0, 1.0), n_samples=1_000_000, seed=42)
+    ref = oracle.integrate(ORC_MOMENTS, oracle.NORMAL, 0.0, 1.0, n_samples=1_000_000, seed=42, guard=1)
+    ok, msg = close(res.values, ref["sums"] / ref["n_eff"], tol=2e-6)
+    assert ok, msg
+
+
+def test_strict_reference_uniform_matches_strict_oracle():
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+
+    integ = MonteCarloIntegrator(strict_reference_uniform=True)
+    res = integ.integrate(MOMENTS, Distribution.normal(0.0, 1.0), n_samples=1_000_000, seed=42)
+    ref = oracle.integrate(ORC_MOMENTS, oracle.NORMAL, 0.0, 1.0, n_samples=1_000_000, seed=42, guard=0)
+    ok, msg = close(res.values, ref["sums"] / ref["n_eff"])
+    assert ok, msg
+
+
+def test_uniform_and_exponential_match_oracle(integrator):
+    from wgpu_montecarlo import Distribution
+
+    fns = [lambda x: x, lambda x: x**2, lambda x: math.sin(x), lambda x: math.exp(-x)]
+    for dist, code, p1, p2 in ((Distribution.uniform(-1.0, 3.0), oracle.UNIFORM, -1.0, 3.0),
+                               (Distribution.exponential(2.0), oracle.EXPONENTIAL, 2.0, 0.0)):
+        res = integrator.integrate(fns, dist, n_samples=2_000_000, seed=7)
+        xs = oracle.samples(code, p1, p2, n_samples=2_000_000, seed=7, guard=1).astype(np.float64)
+        want = [xs.mean(), (xs**2).mean(), np.sin(xs).mean(), np.exp(-xs).mean()]
+        assert res.meta["n_eff"] == xs.size
+        ok, msg = close(res.values, want)
+        assert ok, msg
+
+
+def test_custom_cdf_table_beta_matches_oracle(integrator):
+    """K1 with the 2048-point CDF table of Beta(2,5) (LDS-staged, guide-table search)."""
+    from wgpu_montecarlo import Distribution
+
+    dist = Distribution.beta(2.0, 5.0)
+    fns = [lambda x: x, lambda x: x**2, lambda x: x**3]
+    res = integrator.integrate(fns, dist, n_samples=2_000_000, seed=99)
+    ref = oracle.integrate([(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2), (oracle.FN_POW, 3)], oracle.CUSTOM,
+                           n_samples=2_000_000, seed=99, cdf_table=dist._cdf_table, x_table=dist._x_table, guard=1)
+    assert res.meta["n_eff"] == ref["n_eff"]
+    ok, msg = close(res.values, ref["sums"] / ref["n_eff"], tol=2e-6)
+    assert ok, msg
+    truth = [2 / 7, 2 * 3 / (7 * 8), 2 * 3 * 4 / (7 * 8 * 9)]
+    assert np.all(np.abs(res.values - truth) < 2e-3)
+
+
+def test_custom_cdf_table_not_monotone_uses_reference_search(integrator):
+    """A user CDF table with a dip cannot use the guide table; the capped 12-step search is reproduced."""
+    from wgpu_montecarlo import Distribution
+
+    x = np.linspace(0.0, 1.0, 300, dtype=np.float32)
+    pdf = np.ones_like(x)
+    cdf = np.linspace(0.0, 1.0, 300, dtype=np.float32)
+    cdf[100], cdf[101] = cdf[101], cdf[100]
+    dist = Distribution.from_pdf_table(x, pdf, cdf)
+    res = integrator.integrate([lambda x: x, lambda x: x**2], dist, n_samples=500_000, seed=5)
+    ref = oracle.integrate([(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2)], oracle.CUSTOM, n_samples=500_000, seed=5,
+                           cdf_table=cdf, x_table=x, guard=1)
+    ok, msg = close(res.values, ref["sums"] / ref["n_eff"], tol=2e-6)
+    assert ok, msg
+
+
+def test_importance_sampling_analytic(integrator):
+    """K2, both PDFs analytic (emitted from the Distribution closures)."""
+    from wgpu_montecarlo import Distribution
+
+    target, proposal = Distribution.normal(0.0, 1.0), Distribution.normal(0.5, 1.5)
+    res = integrator.integrate_importance_sampling(MOMENTS, target, proposal, n_samples=2_000_000, seed=11)
+    s2pi = float(np.float32(np.sqrt(2 * np.pi)))
+    ref = oracle.integrate(ORC_MOMENTS, oracle.NORMAL, 0.5, 1.5, n_samples=2_000_000, seed=11, guard=1,
+                           p=(oracle.PDF_NORMAL, 0.0, 1.0, s2pi), q=(oracle.PDF_NORMAL, 0.5, 1.5, s2pi))
+    ok, msg = close(res.values, ref["sums"] / ref["n_eff"])
+    assert ok, msg
+    assert np.all(np.abs(res.values - [0, 1, 0, 3]) < [0.01, 0.02, 0.05, 0.2])
+
+
+def test_importance_sampling_target_table(integrator):
+    """K2 with a 512-point target PDF table (BASELINE config 3 shape, reference tests/test_importance_sampling.py:335-346)."""
+    from wgpu_montecarlo import Distribution
+
+    x = np.linspace(0, 10, 512)
+    target = Distribution.from_pdf_table(x, np.exp(-x))
+    proposal = Distribution.normal(2.0, 3.0)
+    res = integrator.integrate_importance_sampling(MOMENTS, target, proposal, n_samples=2_000_000, seed=3)
+    s2pi = float(np.float32(np.sqrt(2 * np.pi)))
+    ref = oracle.integrate(ORC_MOMENTS, oracle.NORMAL, 2.0, 3.0, n_samples=2_000_000, seed=3, guard=1,
+                           p=(oracle.PDF_TABLE, target._x_table, target._pdf_table),
+                           q=(oracle.PDF_NORMAL, 2.0, 3.0, s2pi))
+    ok, msg = close(res.values, ref["sums"] / ref["n_eff"])
+    assert ok, msg
+    # truth: integral of x^k * exp(-x) on [0,10] ~= 1, 2, 6, 24 minus tails
+    assert abs(res.values[0] - 1.0) < 0.01 and abs(res.values[1] - 2.0) < 0.03
+
+
+def test_importance_sampling_both_tables_nonuniform_grid(integrator):
+    """Both PDFs from tables; the proposal's grid is non-uniform so the binary-search path runs."""
+    from wgpu_montecarlo import Distribution
+
+    xt = np.linspace(-4, 4, 700)
+    target = Distribution.from_pdf_table(xt, np.exp(-0.5 * xt * xt) / np.sqrt(2 * np.pi))
+    xq = np.sign(np.linspace(-1, 1, 901)) * np.abs(np.linspace(-1, 1, 901)) ** 1.5 * 6.0
+    proposal = Distribution.from_pdf_table(xq, np.exp(-0.5 * (xq / 2) ** 2) / (2 * np.sqrt(2 * np.pi)))
+    res = integrator.integrate_importance_sampling([lambda x: x, lambda x: x**2], target, proposal,
+                                                   n_samples=1_000_000, seed=21)
+    ref = oracle.integrate([(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2)], oracle.CUSTOM, n_samples=1_000_000,
+                           seed=21, guard=1, cdf_table=proposal._cdf_table, x_table=proposal._x_table,
+                           p=(oracle.PDF_TABLE, target._x_table, target._pdf_table),
+                           q=(oracle.PDF_TABLE, proposal._x_table, proposal._pdf_table))
+    ok, msg = close(res.values, ref["sums"] / ref["n_eff"])
+    assert ok, msg
+    assert abs(res.values[1] - 1.0) < 0.02
+
+
+def _mcmc_oracle(target, proposal, code, p1, p2, **kw):
+    tx, tl = target.get_log_pdf_table()
+    px, pl = proposal.get_log_pdf_table()
+    return oracle.mcmc([(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2)], code, p1, p2, tx, tl, px, pl,
+                       cdf_table=proposal._cdf_table, x_table=proposal._x_table if proposal._cdf_table is not None else None,
+                       guard=1, **kw)
+
+
+@pytest.mark.parametrize("n_chains,n_steps,n_burnin", [(256, 2000, 200), (1000, 501, 0), (1, 300, 7)])
+def test_mcmc_normal_proposal_matches_oracle(integrator, n_chains, n_steps, n_burnin):
+    """K3: bimodal custom target, normal proposal (BASELINE config 4 shape); padded chain count is bit-exact."""
+    from wgpu_montecarlo import Distribution
+
+    target = Distribution.from_pdf(lambda x: 0.5 * (math.exp(-0.5 * (x - 2) ** 2) + math.exp(-0.5 * (x + 2) ** 2)),
+                                   support=(-10, 10))
+    proposal = Distribution.normal(0.0, 2.0)
+    res = integrator.integrate_mcmc([lambda x: x, lambda x: x**2], target, proposal, n_steps=n_steps,
+                                    n_chains=n_chains, n_burnin=n_burnin, seed=42)
+    ref = _mcmc_oracle(target, proposal, oracle.NORMAL, 0.0, 2.0, n_steps=n_steps, n_chains=n_chains,
+                       n_burnin=n_burnin, seed=42)
+    assert res.meta["n_eff"] == ref["n_eff"] == ((n_chains + 255) // 256) * 256 * n_steps
+    assert res.n_samples == n_chains * n_steps
+    # an accept decision can flip where log(u) and log_alpha agree to ~1 ulp (v_log_f32 vs logf): allow 2e-4
+    ok, msg = close(res.values, ref["sums"][:2] / ref["n_eff"], tol=2e-4)
+    assert ok, msg
+    total_steps = (ref["n_eff"] // n_steps) * (n_steps + n_burnin)
+    assert abs(res.meta["accept_rate"] - ref["sums"][2] / total_steps) < 1e-4
+
+
+@pytest.mark.parametrize("kind", ["uniform", "exponential", "custom"])
+def test_mcmc_other_proposals_match_oracle(integrator, kind):
+    from wgpu_montecarlo import Distribution
+
+    if kind == "uniform":
+        target, proposal, code, p1, p2 = Distribution.beta(2.0, 5.0), Distribution.uniform(0.0, 1.0), oracle.UNIFORM, 0.0, 1.0
+    elif kind == "exponential":
+        target, proposal, code, p1, p2 = Distribution.exponential(1.0), Distribution.exponential(0.5), oracle.EXPONENTIAL, 0.5, 0.0
+    else:
+        target = Distribution.normal(0.0, 1.0)
+        proposal = Distribution.from_pdf(lambda x: math.exp(-abs(x)) / 2, support=(-12, 12))
+        code, p1, p2 = oracle.CUSTOM, 0.0, 0.0
+    res = integrator.integrate_mcmc([lambda x: x, lambda x: x**2], target, proposal, n_steps=1500, n_chains=512,
+                                    n_burnin=100, seed=8)
+    ref = _mcmc_oracle(target, proposal, code, p1, p2, n_steps=1500, n_chains=512, n_burnin=100, seed=8)
+    ok, msg = close(res.values, ref["sums"][:2] / ref["n_eff"], tol=2e-4)
+    assert ok, msg
+
+
+def test_same_call_is_bit_reproducible(integrator):
+    from wgpu_montecarlo import Distribution
+
+    a = integrator.integrate(MOMENTS, Distribution.normal(0.0, 1.0), n_samples=5_000_000, seed=77).values
+    b = integrator.integrate(MOMENTS, Distribution.normal(0.0, 1.0), n_samples=5_000_000, seed=77).values
+    assert np.array_equal(a, b)
+    c = integrator.integrate(MOMENTS, Distribution.normal(0.0, 1.0), n_samples=5_000_000, seed=78).values
+    assert not np.array_equal(a, c)
+
+
+@pytest.mark.parametrize("dist_code", [0, 1, 3])
+def test_shards_partition_the_sample_grid(integrator, dist_code):
+    """Sum over (rank, world) shards == the single-GPU sums: the N-GPU job draws the same samples."""
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo import runtime as rt
+    from wgpu_montecarlo.api import functions_to_hip
+
+    eng = integrator._engine
+    dist = {0: Distribution.uniform(0, 2), 1: Distribution.normal(0, 1), 3: Distribution.beta(2, 5)}[dist_code]
+    cdf = integrator._cdf_table(dist)
+    p1, p2 = {0: (0.0, 2.0), 1: (0.0, 1.0), 3: (0.0, 0.0)}[dist_code]
+    mod = eng.module(functions_to_hip(MOMENTS), rt.make_desc(rt.KIND_INTEGRATE, 4, dist_code))
+    for n in (3_000_001, 70_000):      # L = 46 / 2: the second case has fewer units than 8 ranks for the normal
+        whole, n_eff = eng.integrate(mod, n, 5, p1, p2, cdf=cdf)
+        for world in (2, 3, 8):
+            parts = [eng.integrate(mod, n, 5, p1, p2, cdf=cdf, rank=r, world=world) for r in range(world)]
+            assert all(pe == n_eff for _, pe in parts)
+            total = np.sum([p for p, _ in parts], axis=0)
+            assert np.allclose(total, whole, rtol=1e-8, atol=1e-6), (world, total, whole)  # f32 flush blocks move with the shard boundaries
+
+
+def test_mcmc_chain_shards_partition(integrator):
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo import runtime as rt
+    from wgpu_montecarlo.api import functions_to_hip
+
+    eng = integrator._engine
+    target, proposal = Distribution.normal(0.0, 1.0), Distribution.normal(0.0, 1.5)
+    tt = integrator._table(rt.TABLE_LOGPDF, *target.get_log_pdf_table())
+    qt = integrator._table(rt.TABLE_LOGPDF, *proposal.get_log_pdf_table())
+    mod = eng.module(functions_to_hip(MOMENTS[:2]), rt.make_desc(rt.KIND_MCMC, 2, 1))
+    whole, n_eff = eng.mcmc(mod, 400, 2048, 50, 9, 0.0, 1.5, tt, qt)
+    for world in (2, 3, 8):
+        parts = [eng.mcmc(mod, 400, 2048, 50, 9, 0.0, 1.5, tt, qt, rank=r, world=world)[0] for r in range(world)]
+        assert np.allclose(np.sum(parts, axis=0), whole, rtol=1e-8)
+
+
+def test_full_size_c2_within_three_sigma(integrator):
+    """BASELINE config 2 at full size: n = 1e9, N_eff bit-exact, every moment within 3 sigma of truth."""
+    from wgpu_montecarlo import Distribution
+
+    res = integrator.integrate(MOMENTS, Distribution.normal(0.0, 1.0), n_samples=10**9, seed=42)
+    assert res.meta["n_eff"] == 1_000_013_824
+    sigma = np.sqrt(np.array([1.0, 2.0, 15.0, 96.0]) / res.meta["n_eff"])
+    assert np.all(np.abs(res.values - [0, 1, 0, 3]) < 3 * sigma), res.values
+    # linearity property, size independent: E[2x + 3x^2] == 2 E[x] + 3 E[x^2] on the same stream
+    lin = integrator.integrate([lambda x: 2 * x + 3 * x**2], Distribution.normal(0.0, 1.0), n_samples=10**9, seed=42)
+    assert abs(lin.values[0] - (2 * res.values[0] + 3 * res.values[1])) < 1e-6
+
+
+def test_reference_api_errors(integrator):
+    from wgpu_montecarlo import Distribution
+
+    d = Distribution.normal(0, 1)
+    with pytest.raises(ValueError):
+        integrator.integrate([], d, n_samples=1000)
+    with pytest.raises(TypeError):
+        integrator.integrate([123], d, n_samples=1000)
+    with pytest.raises(ValueError, match="n_steps must be positive"):
+        integrator.integrate_mcmc([lambda x: x], d, d, n_steps=0)
+    with pytest.raises(ValueError, match="n_chains must be positive"):
+        integrator.integrate_mcmc([lambda x: x], d, d, n_chains=0)
+    with pytest.raises(ValueError, match="n_burnin must be non-negative"):
+        integrator.integrate_mcmc([lambda x: x], d, d, n_burnin=-1)
+    with pytest.raises(RuntimeError):
+        integrator.integrate(["fn f(x: f32) -> f32 { return undefined_thing(x); }"], d, n_samples=1000)
+
+
+def test_wgsl_string_functions(integrator):
+    """Raw WGSL function strings (reference tests/test_integrator.py:48-71)."""
+    from wgpu_montecarlo import Distribution
+
+    d = Distribution.normal(0.0, 1.0)
+    res = integrator.integrate([lambda x: x, "fn f(x: f32) -> f32 { return x * x; }"], d, n_samples=1_000_000, seed=42)
+    ref = oracle.integrate([(oracle.FN_IDENTITY, 0), (oracle.FN_SQ, 0)], oracle.NORMAL, 0.0, 1.0, n_samples=1_000_000,
+                           seed=42, guard=1)
+    ok, msg = close(res.values, ref["sums"] / ref["n_eff"])
+    assert ok, msg

@@ -215,6 +215,14 @@ MCX_DEV float mcx_smoothstep(float lo, float hi, float x) {
     return t * t * (3.0f - 2.0f * t);
 }
 MCX_DEV float mcx_select(float f, float t, bool c) { return c ? t : f; }
+MCX_DEV float mcx_degrees(float r) { return r * 57.29577951308232f; }
+MCX_DEV float mcx_radians(float d) { return d * 0.017453292519943295f; }
+// WGSL `%`: truncated remainder for floats (fmodf), the C operator for integers
+template <class A, class B>
+MCX_DEV auto mcx_mod(A a, B b) {
+    if constexpr (__is_integral(A) && __is_integral(B)) return a % b;
+    else return fmodf((float)a, (float)b);
+}
 MCX_DEV float mcx_b2f(bool b) { return b ? 1.0f : 0.0f; }
 MCX_DEV float mcx_b2f(float v) { return v; }
 MCX_DEV float mcx_b2f(int v) { return (float)v; }

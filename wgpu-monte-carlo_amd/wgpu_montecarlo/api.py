@@ -1,0 +1,404 @@
+"""MonteCarloIntegrator / IntegrationResult / convenience functions on MI355X.
+
+Public surface and behaviour follow the reference's python/wgpu_montecarlo/__init__.py:611-1266
+(signatures, defaults, exception types and messages, `n_samples` reporting the request rather than
+T*L, MCMC `n_samples = n_chains * n_steps`). Underneath, nothing is shared with it:
+
+  reference                                          here
+  -------------------------------------------------  -----------------------------------------------
+  callable -> WGSL text (transpiler.py)              callable -> IR -> HIP C++ (frontend.py, emit_hip.py)
+  IS = text wrappers f*p/q, K copies of p and q      IS is a kernel mode: weight p/q once per sample
+  _core.integrate / integrate_is_tables / _mcmc      libmcx.so C ABI via ctypes (runtime.py)
+  one wgpu device, [T][K] f32 readback, CPU f32 mean on-device f64 two-stage reduction, K doubles back
+  --                                                 torch.distributed (RCCL) shard + one all-reduce
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import emit_hip, frontend, runtime, wgsl_to_hip
+from .distributions import Distribution, DistributionType
+from .frontend import TranspilerError
+
+FunctionLike = Union[Callable, str]
+
+# LDS budget for staged tables (csrc/mcx_runtime.cpp MCX_LDS_DYNAMIC_MAX)
+_LDS_TABLE_BUDGET = 64 * 1024 - 2048
+
+
+class IntegrationResult:
+    """Expected values, one per function, in the order the functions were given."""
+
+    def __init__(self, values: np.ndarray, n_samples: int, n_functions: int, meta: Optional[dict] = None):
+        self.values = np.array(values, dtype=np.float64)
+        self.n_samples = n_samples
+        self.n_functions = n_functions
+        self.meta = meta or {}
+
+    def __repr__(self):
+        return f"IntegrationResult(values={self.values}, n_samples={self.n_samples})"
+
+    def __getitem__(self, idx):
+        return self.values[idx]
+
+    def __len__(self):
+        return self.n_functions
+
+
+def _check_seed(seed) -> int:
+    if isinstance(seed, bool) or not isinstance(seed, (int, np.integer)):
+        raise TypeError(f"seed must be an integer, got {type(seed).__name__}")
+    if not 0 <= int(seed) <= 0xFFFFFFFF:
+        raise OverflowError("seed must fit an unsigned 32-bit integer")
+    return int(seed)
+
+
+def _check_count(value, name: str, bits: int = 64) -> int:
+    if isinstance(value, bool) or not isinstance(value, (int, np.integer)):
+        raise TypeError(f"{name} must be an integer, got {type(value).__name__}")
+    if not 0 <= int(value) < (1 << bits):
+        raise OverflowError(f"{name} must fit an unsigned {bits}-bit integer")
+    return int(value)
+
+
+def functions_to_hip(functions: Sequence[FunctionLike], fast_math: bool = False) -> str:
+    """Emit `user_func_0 .. user_func_{K-1}` (HIP C++) for callables and raw WGSL strings."""
+    parts = [emit_hip.prelude()]
+    for i, fn in enumerate(functions):
+        if callable(fn):
+            parts.append(emit_hip.emit_function(frontend.lower(fn), f"user_func_{i}", fast_math))
+        elif isinstance(fn, str):
+            parts.append(wgsl_to_hip.translate(fn, i, f"user_func_{i}"))
+        else:
+            raise TypeError(f"Function must be callable or WGSL string, got {type(fn)}")
+    return "\n\n".join(parts)
+
+
+def _pdf_to_hip(dist: Distribution, name: str, fast_math: bool) -> Optional[str]:
+    """HIP text of a distribution's PDF closure, or None when it is outside the emitter's subset
+    (the reference's table-vs-analytic decision, __init__.py:825-838)."""
+    try:
+        return emit_hip.emit_function(frontend.lower(dist._pdf_func), name, fast_math)
+    except TranspilerError:
+        return None
+
+
+def _dist_params(dist: Distribution):
+    """(code, param1, param2): lib.rs:436-502 including its silent defaults."""
+    code = runtime.DIST_CODES[dist.dist_type.name.lower()]
+    p = dist.params
+
+    def num(key, default):
+        v = p.get(key, default)
+        try:
+            return float(v)
+        except (TypeError, ValueError):
+            return float(default)
+
+    if code == runtime.DIST_UNIFORM:
+        return code, num("min", 0.0), num("max", 1.0)
+    if code == runtime.DIST_NORMAL:
+        return code, num("mean", 0.0), num("std", 1.0)
+    if code == runtime.DIST_EXPONENTIAL:
+        return code, num("lambda", 1.0), 0.0
+    return code, 0.0, 0.0
+
+
+class _Group:
+    """The set of ranks one call is sharded over (torch.distributed; RCCL on GPUs, gloo on CPU)."""
+
+    def __init__(self, process_group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = process_group
+        self.rank = dist.get_rank(process_group)
+        self.world = dist.get_world_size(process_group)
+
+
+def _default_group():
+    """Shard over the default process group when the caller has initialised torch.distributed."""
+    import sys
+
+    torch = sys.modules.get("torch")
+    if torch is None or os.environ.get("MCX_DISTRIBUTED", "1") == "0":
+        return None
+    dist = getattr(torch, "distributed", None)
+    if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() < 2:
+        return None
+    return _Group()
+
+
+class MonteCarloIntegrator:
+    """Fused multi-function Monte-Carlo integrator on one MI355X (or one rank of N).
+
+    Args:
+        target_threads: logical thread count T of the reference's sample grid (default 65536). It
+            fixes the sample indexing (T, L = ceil(n/T)), not the physical launch geometry.
+        device: HIP device index (default: LOCAL_RANK if set, else 0).
+        process_group: torch.distributed group to shard over; default = the world group when
+            torch.distributed is initialised, else single GPU.
+        math: "default" (ocml functions in user code) or "fast" (hardware sin/cos/exp/log).
+        strict_reference_uniform: reproduce u = float(hash)*2^-32 on the closed interval [0,1]
+            (reference behaviour, can produce log(0)); default False guards the end points.
+    """
+
+    def __init__(self, target_threads: Optional[int] = None, device: Optional[int] = None, process_group=None,
+                 math: str = "default", strict_reference_uniform: bool = False):
+        try:
+            runtime.load()
+        except ImportError:
+            raise
+        if math not in ("default", "fast", "precise"):
+            raise ValueError("math must be 'default', 'fast' or 'precise'")
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if runtime.device_count() > 1 else 0
+        self._engine = runtime.Engine(device)       # RuntimeError("Failed to initialize GPU: ...") without a GPU
+        self._integrator = self._engine             # attribute name the reference uses for its native object
+        self._target_threads = target_threads
+        self._fast_math = math == "fast"
+        self._precise_sampler = math == "precise"
+        self._guard = not strict_reference_uniform
+        self._group = _Group(process_group) if process_group is not None else _default_group()
+        self._tables = {}
+
+    # ---- helpers ---------------------------------------------------------------------------------
+    def _table(self, kind: int, keys: np.ndarray, values: np.ndarray) -> runtime.Table:
+        keys = np.ascontiguousarray(keys, dtype=np.float32)
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        key = (kind, keys.tobytes(), values.tobytes())
+        tb = self._tables.get(key)
+        if tb is None:
+            if len(self._tables) > 64:
+                self._tables.clear()
+            tb = self._engine.table(kind, keys, values)
+            self._tables[key] = tb
+        return tb
+
+    def _cdf_table(self, dist: Distribution) -> Optional[runtime.Table]:
+        if dist.dist_type != DistributionType.CUSTOM:
+            return None
+        if dist._x_table is None or dist._cdf_table is None:
+            raise ValueError("custom distribution has no CDF table")
+        return self._table(runtime.TABLE_CDF, dist._cdf_table, dist._x_table)
+
+    @staticmethod
+    def _lds_bytes(*tables: Optional[runtime.Table]) -> int:
+        total = 0
+        for tb in tables:
+            if tb is None:
+                continue
+            total += tb.n * 8
+            bits = tb.info()["guide_bits"]
+            if bits:
+                total += (((1 << bits) + 2) & ~1) * 4
+        return total
+
+    def _run(self, rows: int, call):
+        """Run one sharded launch and combine the ranks with ONE sum all-reduce of `rows` doubles.
+
+        call(d_sums, stream) -> (host sums or None, n_eff). With an RCCL group the partial sums never
+        leave the GPU before the collective: the kernels write them to a torch CUDA buffer on torch's
+        current stream and the all-reduce runs on that buffer over xGMI."""
+        g = self._group
+        if g is None or g.world < 2:
+            sums, n_eff = call(None, None)
+            return sums / float(n_eff), n_eff
+        import torch
+
+        if g.dist.get_backend(g.group) == "nccl":
+            dev = torch.device("cuda", self._engine.device)
+            buf = torch.empty(rows, dtype=torch.float64, device=dev)
+            stream = torch.cuda.current_stream(dev)
+            _, n_eff = call(buf.data_ptr(), stream.cuda_stream)
+            g.dist.all_reduce(buf, op=g.dist.ReduceOp.SUM, group=g.group)
+            sums = buf.cpu().numpy()
+        else:                                   # gloo: host tensors (CPU rehearsal of the N > 1 path)
+            sums, n_eff = call(None, None)
+            t = torch.from_numpy(np.ascontiguousarray(sums))
+            g.dist.all_reduce(t, op=g.dist.ReduceOp.SUM, group=g.group)
+            sums = t.numpy()
+        return sums / float(n_eff), n_eff
+
+    def _rank_world(self):
+        return (self._group.rank, self._group.world) if self._group is not None else (0, 1)
+
+    # ---- K1 ----------------------------------------------------------------------------------------
+    def integrate(self, functions: List[FunctionLike], distribution: Distribution, n_samples: int = 1_000_000,
+                  seed: int = 42) -> IntegrationResult:
+        """E[f_k(X)], X ~ distribution, for all functions on the same samples."""
+        if len(functions) == 0:
+            raise ValueError("At least one function is required")
+        user_src = functions_to_hip(functions, self._fast_math)
+        n_samples = _check_count(n_samples, "n_samples")
+        seed = _check_seed(seed)
+        code, p1, p2 = _dist_params(distribution)
+        cdf = self._cdf_table(distribution)
+        lds_ok = self._lds_bytes(cdf) <= _LDS_TABLE_BUDGET
+        desc = runtime.make_desc(runtime.KIND_INTEGRATE, len(functions), code, guard_endpoints=self._guard,
+                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok)
+        mod = self._engine.module(user_src, desc)
+        rank, world = self._rank_world()
+        values, n_eff = self._run(len(functions), lambda d_sums, stream: self._engine.integrate(
+            mod, n_samples, seed, p1, p2, self._target_threads, cdf=cdf, rank=rank, world=world,
+            d_sums=d_sums, stream=stream))
+        return IntegrationResult(values, n_samples, len(functions), self._meta(n_eff))
+
+    # ---- K2 ----------------------------------------------------------------------------------------
+    def integrate_importance_sampling(self, functions: List[FunctionLike], target_distribution: Distribution,
+                                      proposal_distribution: Distribution, n_samples: int = 1_000_000,
+                                      seed: int = 42) -> IntegrationResult:
+        """E_p[f_k(X)] ~= mean f_k(x) p(x)/q(x), x ~ q."""
+        if len(functions) == 0:
+            raise ValueError("At least one function is required")
+        p_src = _pdf_to_hip(target_distribution, "mcx_pdf_p", self._fast_math)
+        q_src = _pdf_to_hip(proposal_distribution, "mcx_pdf_q", self._fast_math)
+        user_src = functions_to_hip(functions, self._fast_math)
+        n_samples = _check_count(n_samples, "n_samples")
+        seed = _check_seed(seed)
+        code, p1, p2 = _dist_params(proposal_distribution)
+        cdf = self._cdf_table(proposal_distribution)
+        p_table = q_table = None
+        if p_src is None:
+            xs, dens = target_distribution.get_or_compute_pdf_table()
+            p_table = self._table(runtime.TABLE_PDF, xs, dens)
+        else:
+            user_src += "\n\n" + p_src
+        if q_src is None:
+            xs, dens = proposal_distribution.get_or_compute_pdf_table()
+            q_table = self._table(runtime.TABLE_PDF, xs, dens)
+        else:
+            user_src += "\n\n" + q_src
+        lds_ok = self._lds_bytes(cdf, p_table, q_table) <= _LDS_TABLE_BUDGET
+        desc = runtime.make_desc(runtime.KIND_INTEGRATE, len(functions), code, weight=True,
+                                 p_table=p_table is not None, q_table=q_table is not None,
+                                 guard_endpoints=self._guard, precise_sampler=self._precise_sampler,
+                                 tables_lds=lds_ok)
+        mod = self._engine.module(user_src, desc)
+        rank, world = self._rank_world()
+        values, n_eff = self._run(len(functions), lambda d_sums, stream: self._engine.integrate(
+            mod, n_samples, seed, p1, p2, self._target_threads, cdf=cdf, target_pdf=p_table,
+            proposal_pdf=q_table, rank=rank, world=world, d_sums=d_sums, stream=stream))
+        return IntegrationResult(values, n_samples, len(functions), self._meta(n_eff))
+
+    # ---- K3 ----------------------------------------------------------------------------------------
+    def integrate_mcmc(self, functions: List[FunctionLike], target_distribution: Distribution,
+                       proposal_distribution: Distribution, n_steps: int = 10_000, n_chains: int = 1024,
+                       n_burnin: int = 1_000, seed: int = 42) -> IntegrationResult:
+        """E_p[f_k(X)] by independent-proposal Metropolis-Hastings, one chain per logical thread."""
+        if len(functions) == 0:
+            raise ValueError("At least one function is required")
+        if n_steps <= 0:
+            raise ValueError("n_steps must be positive")
+        if n_chains <= 0:
+            raise ValueError("n_chains must be positive")
+        if n_burnin < 0:
+            raise ValueError("n_burnin must be non-negative")
+        user_src = functions_to_hip(functions, self._fast_math)
+        n_steps = _check_count(n_steps, "n_steps", 32)
+        n_chains = _check_count(n_chains, "n_chains", 32)
+        n_burnin = _check_count(n_burnin, "n_burnin", 32)
+        seed = _check_seed(seed)
+        tx, tlog = target_distribution.get_log_pdf_table()
+        px, plog = proposal_distribution.get_log_pdf_table()
+        t_table = self._table(runtime.TABLE_LOGPDF, tx, tlog)
+        q_table = self._table(runtime.TABLE_LOGPDF, px, plog)
+        code, p1, p2 = _dist_params(proposal_distribution)
+        cdf = self._cdf_table(proposal_distribution)
+        lds_ok = self._lds_bytes(cdf, t_table, q_table) <= _LDS_TABLE_BUDGET
+        desc = runtime.make_desc(runtime.KIND_MCMC, len(functions), code, guard_endpoints=self._guard,
+                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok)
+        mod = self._engine.module(user_src, desc)
+        rank, world = self._rank_world()
+        k = len(functions)
+        values, n_eff = self._run(k + 1, lambda d_sums, stream: self._engine.mcmc(
+            mod, n_steps, n_chains, n_burnin, seed, p1, p2, t_table, q_table,
+            target_threads=self._target_threads, cdf=cdf, rank=rank, world=world, d_sums=d_sums, stream=stream))
+        meta = self._meta(n_eff)
+        total_chains = n_eff // n_steps
+        meta["accept_rate"] = float(values[k]) * n_eff / (float(total_chains) * (n_steps + n_burnin))
+        return IntegrationResult(values[:k], n_chains * n_steps, k, meta)
+
+    # ---- prepared (asynchronous) form of K1 ---------------------------------------------------------
+    def prepare_integrate(self, functions: List[FunctionLike], distribution: Distribution) -> "PreparedIntegrand":
+        """Emit + compile once; the returned object launches without host synchronisation.
+
+        Extension over the reference API for serving / benchmarking loops: every `integrate()` call of the
+        reference re-transpiles and re-compiles (src/engine.rs:325-331)."""
+        if len(functions) == 0:
+            raise ValueError("At least one function is required")
+        user_src = functions_to_hip(functions, self._fast_math)
+        code, p1, p2 = _dist_params(distribution)
+        cdf = self._cdf_table(distribution)
+        lds_ok = self._lds_bytes(cdf) <= _LDS_TABLE_BUDGET
+        desc = runtime.make_desc(runtime.KIND_INTEGRATE, len(functions), code, guard_endpoints=self._guard,
+                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok)
+        return PreparedIntegrand(self, self._engine.module(user_src, desc), len(functions), p1, p2, cdf)
+
+    def _meta(self, n_eff: int) -> dict:
+        launch = self._engine.last_launch()
+        rank, world = self._rank_world()
+        return dict(n_eff=n_eff, kernel_ms=self._engine.last_kernel_ms(), n_blocks=launch["n_blocks"],
+                    block=launch["block"], lds_bytes=launch["lds_bytes"], rank=rank, world=world)
+
+
+class PreparedIntegrand:
+    """A compiled fused integrand bound to one engine (see MonteCarloIntegrator.prepare_integrate)."""
+
+    def __init__(self, owner: MonteCarloIntegrator, module: runtime.Module, k: int, p1: float, p2: float,
+                 cdf: Optional[runtime.Table]):
+        self._owner, self._module, self.k = owner, module, k
+        self._p1, self._p2, self._cdf = p1, p2, cdf
+
+    def launch(self, n_samples: int, seed: int, out) -> int:
+        """Enqueue sampling + reduction (+ one sum all-reduce when sharded) on torch's current stream.
+
+        `out` is a float64 CUDA tensor with k elements that receives the SUMS over the whole job (all
+        ranks); divide by the returned n_eff for the expected values. No host synchronisation."""
+        import torch
+
+        owner = self._owner
+        rank, world = owner._rank_world()
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+        _, n_eff = owner._engine.integrate(self._module, n_samples, seed, self._p1, self._p2,
+                                           owner._target_threads, cdf=self._cdf, rank=rank, world=world,
+                                           d_sums=out.data_ptr(), stream=stream)
+        if world > 1:
+            g = owner._group
+            g.dist.all_reduce(out, op=g.dist.ReduceOp.SUM, group=g.group)
+        return n_eff
+
+    def run(self, n_samples: int, seed: int = 42) -> IntegrationResult:
+        """Blocking form: same result as MonteCarloIntegrator.integrate()."""
+        owner = self._owner
+        rank, world = owner._rank_world()
+        values, n_eff = owner._run(self.k, lambda d_sums, stream: owner._engine.integrate(
+            self._module, n_samples, seed, self._p1, self._p2, owner._target_threads, cdf=self._cdf,
+            rank=rank, world=world, d_sums=d_sums, stream=stream))
+        return IntegrationResult(values, n_samples, self.k, owner._meta(n_eff))
+
+
+def integrate(functions: List[FunctionLike], distribution: Distribution, n_samples: int = 1_000_000, seed: int = 42,
+              target_threads: Optional[int] = None) -> IntegrationResult:
+    """Shorthand for MonteCarloIntegrator(target_threads).integrate(...)."""
+    return MonteCarloIntegrator(target_threads=target_threads).integrate(functions, distribution, n_samples, seed)
+
+
+def integrate_importance_sampling(functions: List[FunctionLike], target_distribution: Distribution,
+                                  proposal_distribution: Distribution, n_samples: int = 1_000_000, seed: int = 42,
+                                  target_threads: Optional[int] = None) -> IntegrationResult:
+    """Shorthand for MonteCarloIntegrator(target_threads).integrate_importance_sampling(...)."""
+    return MonteCarloIntegrator(target_threads=target_threads).integrate_importance_sampling(
+        functions, target_distribution, proposal_distribution, n_samples, seed)
+
+
+def integrate_mcmc(functions: List[FunctionLike], target_distribution: Distribution,
+                   proposal_distribution: Distribution, n_steps: int = 10_000, n_chains: int = 1024,
+                   n_burnin: int = 1_000, seed: int = 42, target_threads: Optional[int] = None) -> IntegrationResult:
+    """Shorthand for MonteCarloIntegrator(target_threads).integrate_mcmc(...). As in the reference,
+    target_threads (if given) overrides n_chains (src/engine.rs:860)."""
+    return MonteCarloIntegrator(target_threads=target_threads).integrate_mcmc(
+        functions, target_distribution, proposal_distribution, n_steps, n_chains, n_burnin, seed)

@@ -1,0 +1,324 @@
+"""ctypes binding of libmcx.so (C ABI: include/mcx.h).
+
+This is the seam where the reference crosses from Python into its PyO3 module
+`wgpu_montecarlo._core` (reference __init__.py:49-57, src/lib.rs:516-520). There is no CPU fallback:
+if the shared library is missing the import fails, and if no gfx950 GPU is visible creating an engine
+raises RuntimeError("Failed to initialize GPU: ...") exactly where the reference does (src/lib.rs:26-28).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("MCX_LIBRARY", str(_PKG_DIR / "libmcx.so")))
+
+DIST_UNIFORM, DIST_NORMAL, DIST_EXPONENTIAL, DIST_CUSTOM = 0, 1, 2, 3
+TABLE_CDF, TABLE_PDF, TABLE_LOGPDF = 0, 1, 2
+KIND_INTEGRATE, KIND_MCMC = 0, 1
+
+E_INVALID, E_RUNTIME, E_COMPILE, E_NODEVICE = -1, -2, -3, -4
+
+DIST_CODES = {"uniform": DIST_UNIFORM, "normal": DIST_NORMAL, "exponential": DIST_EXPONENTIAL, "custom": DIST_CUSTOM}
+
+
+class Dispatch(C.Structure):
+    _fields_ = [("workgroup_size", C.c_uint32), ("workgroup_count", C.c_uint32),
+                ("loops_per_thread", C.c_uint32), ("total_threads", C.c_uint32)]
+
+
+class Shard(C.Structure):
+    _fields_ = [("idx_begin", C.c_uint32), ("idx_count", C.c_uint32),
+                ("unit_begin", C.c_uint32), ("unit_end", C.c_uint32)]
+
+
+class ModuleDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("dist_type", C.c_int32), ("weight", C.c_int32),
+                ("p_table", C.c_int32), ("q_table", C.c_int32), ("guard_endpoints", C.c_int32),
+                ("precise_sampler", C.c_int32), ("block", C.c_int32), ("tables_lds", C.c_int32)]
+
+
+class IntegrateParams(C.Structure):
+    _fields_ = [("n_samples", C.c_uint64), ("target_threads", C.c_int64), ("seed", C.c_uint32),
+                ("param1", C.c_float), ("param2", C.c_float), ("rank", C.c_uint32), ("world", C.c_uint32),
+                ("cdf", C.c_void_p), ("target_pdf", C.c_void_p), ("proposal_pdf", C.c_void_p)]
+
+
+class McmcParams(C.Structure):
+    _fields_ = [("n_steps", C.c_uint32), ("n_chains", C.c_uint32), ("n_burnin", C.c_uint32),
+                ("target_threads", C.c_int64), ("seed", C.c_uint32), ("param1", C.c_float),
+                ("param2", C.c_float), ("rank", C.c_uint32), ("world", C.c_uint32),
+                ("cdf", C.c_void_p), ("target_logpdf", C.c_void_p), ("proposal_logpdf", C.c_void_p)]
+
+
+# every symbol include/mcx.h declares (tests check that the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "mcx_version", "mcx_last_error", "mcx_dispatch_config", "mcx_mcmc_dispatch_config", "mcx_shard_integrate",
+    "mcx_shard_chains", "mcx_device_count", "mcx_engine_create", "mcx_engine_destroy", "mcx_engine_device",
+    "mcx_engine_last_kernel_ms", "mcx_engine_last_launch", "mcx_engine_set_target_threads", "mcx_module_build",
+    "mcx_module_precompile", "mcx_module_source", "mcx_free", "mcx_module_release", "mcx_cache_dir",
+    "mcx_table_create", "mcx_table_release", "mcx_table_info", "mcx_integrate", "mcx_integrate_device",
+    "mcx_mcmc", "mcx_mcmc_device",
+]
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load():
+    """Load libmcx.so (raises ImportError if it has not been built)."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"libmcx.so not found at {LIB_PATH}. Build it with `make -C wgpu-monte-carlo_amd/csrc` "
+                f"(or `python -c 'import __graft_entry__ as g; g.build()'`)."
+            )
+        try:
+            L = C.CDLL(str(LIB_PATH))
+        except OSError as exc:
+            raise ImportError(f"could not load {LIB_PATH}: {exc}")
+        vp, u32, i64, u64 = C.c_void_p, C.c_uint32, C.c_int64, C.c_uint64
+        L.mcx_version.restype = C.c_char_p
+        L.mcx_last_error.restype = C.c_char_p
+        L.mcx_cache_dir.restype = C.c_char_p
+        L.mcx_dispatch_config.argtypes = [u64, i64, C.POINTER(Dispatch)]
+        L.mcx_mcmc_dispatch_config.argtypes = [u32, i64, C.POINTER(Dispatch)]
+        L.mcx_shard_integrate.argtypes = [C.POINTER(Dispatch), C.c_int, u32, u32, C.POINTER(Shard)]
+        L.mcx_shard_chains.argtypes = [u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
+        L.mcx_engine_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.mcx_engine_destroy.argtypes = [vp]
+        L.mcx_engine_destroy.restype = None
+        L.mcx_engine_device.argtypes = [vp]
+        L.mcx_engine_last_kernel_ms.argtypes = [vp]
+        L.mcx_engine_last_kernel_ms.restype = C.c_float
+        L.mcx_engine_last_launch.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+        L.mcx_engine_set_target_threads.argtypes = [vp, u32]
+        L.mcx_module_build.argtypes = [vp, C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(vp)]
+        L.mcx_module_precompile.argtypes = [C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(C.c_int)]
+        L.mcx_module_source.argtypes = [C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(vp)]
+        L.mcx_free.argtypes = [vp]
+        L.mcx_free.restype = None
+        L.mcx_module_release.argtypes = [vp]
+        L.mcx_module_release.restype = None
+        L.mcx_table_create.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), u32, C.POINTER(vp)]
+        L.mcx_table_release.argtypes = [vp]
+        L.mcx_table_release.restype = None
+        L.mcx_table_info.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(u32)]
+        L.mcx_integrate.argtypes = [vp, vp, C.POINTER(IntegrateParams), C.POINTER(C.c_double), C.POINTER(u64)]
+        L.mcx_integrate_device.argtypes = [vp, vp, C.POINTER(IntegrateParams), vp, vp, C.POINTER(u64)]
+        L.mcx_mcmc.argtypes = [vp, vp, C.POINTER(McmcParams), C.POINTER(C.c_double), C.POINTER(u64)]
+        L.mcx_mcmc_device.argtypes = [vp, vp, C.POINTER(McmcParams), vp, vp, C.POINTER(u64)]
+        _lib = L
+        return _lib
+
+
+def last_error() -> str:
+    return (load().mcx_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    """Map a C status to the exception type the reference raises for the same condition."""
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == E_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+# ---- planning helpers (no GPU needed) ---------------------------------------------------------------
+def dispatch_config(n_samples: int, target_threads: Optional[int] = None) -> Dispatch:
+    d = Dispatch()
+    check(load().mcx_dispatch_config(int(n_samples), int(target_threads or 0), C.byref(d)))
+    return d
+
+
+def mcmc_dispatch_config(n_chains: int, target_threads: Optional[int] = None) -> Dispatch:
+    d = Dispatch()
+    check(load().mcx_mcmc_dispatch_config(int(n_chains), int(target_threads or 0), C.byref(d)))
+    return d
+
+
+def shard_integrate(d: Dispatch, dist_type: int, rank: int, world: int) -> Shard:
+    s = Shard()
+    check(load().mcx_shard_integrate(C.byref(d), int(dist_type), int(rank), int(world), C.byref(s)))
+    return s
+
+
+def shard_chains(total_chains: int, rank: int, world: int):
+    b, n = C.c_uint32(0), C.c_uint32(0)
+    check(load().mcx_shard_chains(int(total_chains), int(rank), int(world), C.byref(b), C.byref(n)))
+    return int(b.value), int(n.value)
+
+
+def make_desc(kind: int, k: int, dist_type: int, weight: bool = False, p_table: bool = False,
+              q_table: bool = False, guard_endpoints: bool = True, precise_sampler: bool = False,
+              block: int = 0, tables_lds: bool = True) -> ModuleDesc:
+    return ModuleDesc(kind, k, dist_type, int(weight), int(p_table), int(q_table), int(guard_endpoints),
+                      int(precise_sampler), int(block), int(tables_lds))
+
+
+def module_source(user_src: str, desc: ModuleDesc) -> str:
+    out = C.c_void_p()
+    check(load().mcx_module_source(user_src.encode(), C.byref(desc), C.byref(out)))
+    try:
+        return C.string_at(out).decode()
+    finally:
+        load().mcx_free(out)
+
+
+def precompile(user_src: str, desc: ModuleDesc) -> int:
+    """hiprtc-compile into the disk cache (no GPU needed). Returns 0 = compiled, 1 = memory hit, 2 = disk hit."""
+    hit = C.c_int(0)
+    check(load().mcx_module_precompile(user_src.encode(), C.byref(desc), C.byref(hit)))
+    return int(hit.value)
+
+
+def device_count() -> int:
+    return int(load().mcx_device_count())
+
+
+# ---- handles ---------------------------------------------------------------------------------------
+class Table:
+    def __init__(self, engine: "Engine", kind: int, keys: np.ndarray, values: np.ndarray):
+        keys = np.ascontiguousarray(keys, dtype=np.float32)
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        if keys.shape != values.shape or keys.ndim != 1:
+            raise ValueError("table keys and values must be 1D arrays of the same length")
+        self._engine = engine
+        self._h = C.c_void_p()
+        fp = C.POINTER(C.c_float)
+        check(load().mcx_table_create(engine._h, kind, keys.ctypes.data_as(fp), values.ctypes.data_as(fp),
+                                      len(keys), C.byref(self._h)))
+        self.kind, self.n = kind, len(keys)
+
+    def info(self) -> dict:
+        n, inv, bits = C.c_uint32(), C.c_float(), C.c_uint32()
+        check(load().mcx_table_info(self._h, C.byref(n), C.byref(inv), C.byref(bits)))
+        return dict(n=n.value, inv_dk=inv.value, guide_bits=bits.value)
+
+    def release(self) -> None:
+        if self._h:
+            load().mcx_table_release(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class Module:
+    def __init__(self, engine: "Engine", user_src: str, desc: ModuleDesc):
+        self._engine = engine
+        self.desc = desc
+        self._h = C.c_void_p()
+        check(load().mcx_module_build(engine._h, user_src.encode(), C.byref(desc), C.byref(self._h)))
+
+    def release(self) -> None:
+        if self._h:
+            load().mcx_module_release(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One GPU + one stream (replaces the reference's ComputeEngine, src/engine.rs:70-131)."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        check(load().mcx_engine_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+        self._modules = {}
+
+    def module(self, user_src: str, desc: ModuleDesc) -> Module:
+        key = (user_src, bytes(desc))
+        mod = self._modules.get(key)
+        if mod is None:
+            mod = Module(self, user_src, desc)
+            if len(self._modules) > 256:
+                self._modules.clear()
+            self._modules[key] = mod
+        return mod
+
+    def table(self, kind: int, keys, values) -> Table:
+        return Table(self, kind, keys, values)
+
+    def set_target_threads(self, n: int) -> None:
+        check(load().mcx_engine_set_target_threads(self._h, int(n)))
+
+    def last_kernel_ms(self) -> float:
+        return float(load().mcx_engine_last_kernel_ms(self._h))
+
+    def last_launch(self) -> dict:
+        nb, b, lds = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(load().mcx_engine_last_launch(self._h, C.byref(nb), C.byref(b), C.byref(lds)))
+        return dict(n_blocks=nb.value, block=b.value, lds_bytes=lds.value)
+
+    @staticmethod
+    def _ptr(t: Optional[Table]):
+        return t._h if t is not None else None
+
+    def integrate(self, mod: Module, n_samples: int, seed: int, param1: float, param2: float,
+                  target_threads: Optional[int] = None, cdf: Optional[Table] = None,
+                  target_pdf: Optional[Table] = None, proposal_pdf: Optional[Table] = None,
+                  rank: int = 0, world: int = 1, d_sums: Optional[int] = None, stream: Optional[int] = None):
+        """Returns (sums float64[K] or None when d_sums is given, n_eff)."""
+        p = IntegrateParams(int(n_samples), int(target_threads or 0), int(seed) & 0xFFFFFFFF, float(param1),
+                            float(param2), int(rank), int(world), self._ptr(cdf), self._ptr(target_pdf),
+                            self._ptr(proposal_pdf))
+        n_eff = C.c_uint64(0)
+        if d_sums is not None:
+            check(load().mcx_integrate_device(self._h, mod._h, C.byref(p), C.c_void_p(d_sums),
+                                              C.c_void_p(stream or 0), C.byref(n_eff)))
+            return None, int(n_eff.value)
+        sums = np.zeros(mod.desc.k, dtype=np.float64)
+        check(load().mcx_integrate(self._h, mod._h, C.byref(p), sums.ctypes.data_as(C.POINTER(C.c_double)),
+                                   C.byref(n_eff)))
+        return sums, int(n_eff.value)
+
+    def mcmc(self, mod: Module, n_steps: int, n_chains: int, n_burnin: int, seed: int, param1: float,
+             param2: float, target_logpdf: Table, proposal_logpdf: Table, target_threads: Optional[int] = None,
+             cdf: Optional[Table] = None, rank: int = 0, world: int = 1, d_sums: Optional[int] = None,
+             stream: Optional[int] = None):
+        """Returns (sums float64[K+1] (last = accepted steps) or None, n_eff)."""
+        p = McmcParams(int(n_steps), int(n_chains), int(n_burnin), int(target_threads or 0),
+                       int(seed) & 0xFFFFFFFF, float(param1), float(param2), int(rank), int(world),
+                       self._ptr(cdf), self._ptr(target_logpdf), self._ptr(proposal_logpdf))
+        n_eff = C.c_uint64(0)
+        if d_sums is not None:
+            check(load().mcx_mcmc_device(self._h, mod._h, C.byref(p), C.c_void_p(d_sums),
+                                         C.c_void_p(stream or 0), C.byref(n_eff)))
+            return None, int(n_eff.value)
+        sums = np.zeros(mod.desc.k + 1, dtype=np.float64)
+        check(load().mcx_mcmc(self._h, mod._h, C.byref(p), sums.ctypes.data_as(C.POINTER(C.c_double)),
+                              C.byref(n_eff)))
+        return sums, int(n_eff.value)
+
+    def close(self) -> None:
+        for mod in list(self._modules.values()):
+            mod.release()
+        self._modules.clear()
+        if self._h:
+            load().mcx_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
