@@ -19,7 +19,7 @@ from typing import Callable, List, Optional, Sequence, Union
 
 import numpy as np
 
-from . import emit_hip, frontend, runtime, wgsl_to_hip
+from . import distributed, emit_hip, frontend, runtime, wgsl_to_hip
 from .distributions import Distribution, DistributionType
 from .frontend import TranspilerError
 
@@ -107,31 +107,6 @@ def _dist_params(dist: Distribution):
     return code, 0.0, 0.0
 
 
-class _Group:
-    """The set of ranks one call is sharded over (torch.distributed; RCCL on GPUs, gloo on CPU)."""
-
-    def __init__(self, process_group=None):
-        import torch.distributed as dist
-
-        self.dist = dist
-        self.group = process_group
-        self.rank = dist.get_rank(process_group)
-        self.world = dist.get_world_size(process_group)
-
-
-def _default_group():
-    """Shard over the default process group when the caller has initialised torch.distributed."""
-    import sys
-
-    torch = sys.modules.get("torch")
-    if torch is None or os.environ.get("MCX_DISTRIBUTED", "1") == "0":
-        return None
-    dist = getattr(torch, "distributed", None)
-    if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() < 2:
-        return None
-    return _Group()
-
-
 class MonteCarloIntegrator:
     """Fused multi-function Monte-Carlo integrator on one MI355X (or one rank of N).
 
@@ -162,7 +137,7 @@ class MonteCarloIntegrator:
         self._fast_math = math == "fast"
         self._precise_sampler = math == "precise"
         self._guard = not strict_reference_uniform
-        self._group = _Group(process_group) if process_group is not None else _default_group()
+        self._group = distributed.Group(process_group) if process_group is not None else distributed.default_group()
         self._tables = {}
 
     # ---- helpers ---------------------------------------------------------------------------------
@@ -207,20 +182,17 @@ class MonteCarloIntegrator:
         if g is None or g.world < 2:
             sums, n_eff = call(None, None)
             return sums / float(n_eff), n_eff
-        import torch
+        if g.backend == "nccl":
+            import torch
 
-        if g.dist.get_backend(g.group) == "nccl":
             dev = torch.device("cuda", self._engine.device)
             buf = torch.empty(rows, dtype=torch.float64, device=dev)
-            stream = torch.cuda.current_stream(dev)
-            _, n_eff = call(buf.data_ptr(), stream.cuda_stream)
-            g.dist.all_reduce(buf, op=g.dist.ReduceOp.SUM, group=g.group)
+            _, n_eff = call(buf.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+            distributed.all_reduce_device(g, buf)
             sums = buf.cpu().numpy()
         else:                                   # gloo: host tensors (CPU rehearsal of the N > 1 path)
             sums, n_eff = call(None, None)
-            t = torch.from_numpy(np.ascontiguousarray(sums))
-            g.dist.all_reduce(t, op=g.dist.ReduceOp.SUM, group=g.group)
-            sums = t.numpy()
+            sums = distributed.all_reduce_host(g, sums)
         return sums / float(n_eff), n_eff
 
     def _rank_world(self):
@@ -367,8 +339,7 @@ class PreparedIntegrand:
                                            owner._target_threads, cdf=self._cdf, rank=rank, world=world,
                                            d_sums=out.data_ptr(), stream=stream)
         if world > 1:
-            g = owner._group
-            g.dist.all_reduce(out, op=g.dist.ReduceOp.SUM, group=g.group)
+            distributed.all_reduce_device(owner._group, out)
         return n_eff
 
     def run(self, n_samples: int, seed: int = 42) -> IntegrationResult:
