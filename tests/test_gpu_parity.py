@@ -243,7 +243,8 @@ def test_shards_partition_the_sample_grid(integrator, dist_code):
             parts = [eng.integrate(mod, n, 5, p1, p2, cdf=cdf, rank=r, world=world) for r in range(world)]
             assert all(pe == n_eff for _, pe in parts)
             total = np.sum([p for p, _ in parts], axis=0)
-            assert np.allclose(total, whole, rtol=1e-8, atol=1e-6), (world, total, whole)  # f32 flush blocks move with the shard boundaries
+            # f32 flush blocks move with the shard boundaries: compare relative to the summed magnitude (~N_eff)
+            assert np.allclose(total, whole, rtol=1e-8, atol=1e-9 * n_eff), (world, total, whole)
 
 
 def test_mcmc_chain_shards_partition(integrator):
@@ -259,7 +260,7 @@ def test_mcmc_chain_shards_partition(integrator):
     whole, n_eff = eng.mcmc(mod, 400, 2048, 50, 9, 0.0, 1.5, tt, qt)
     for world in (2, 3, 8):
         parts = [eng.mcmc(mod, 400, 2048, 50, 9, 0.0, 1.5, tt, qt, rank=r, world=world)[0] for r in range(world)]
-        assert np.allclose(np.sum(parts, axis=0), whole, rtol=1e-8)
+        assert np.allclose(np.sum(parts, axis=0), whole, rtol=1e-8, atol=1e-9 * n_eff)
 
 
 def test_full_size_c2_within_three_sigma(integrator):

@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Run the BASELINE.json configurations C1..C5 at full size through the public API on one MI355X and print
+one JSON line per config: values, truth, |err| vs 3 sigma, kernel time, samples (or MH steps) per second.
+
+    python tools/run_configs.py [--only C2,C4] [--repeat 3]
+"""
+import argparse
+import json
+import math
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "wgpu-monte-carlo_amd"))
+
+from wgpu_montecarlo import Distribution, MonteCarloIntegrator  # noqa: E402
+
+
+def bimodal(x):
+    return 0.5 * (math.exp(-0.5 * (x - 2) ** 2) + math.exp(-0.5 * (x + 2) ** 2))
+
+
+def table_moments(xs, ps, qpdf, kmax):
+    """mu_k = integral x^k p~(x) dx for the piecewise-linear interpolant p~, and the IS variance
+    integral (x^k p~/q)^2 q dx - mu_k^2, by 4-point Gauss-Legendre on each table cell (+ fine sub-cells)."""
+    gx, gw = np.polynomial.legendre.leggauss(4)
+    sub = 8
+    mus, variances = [], []
+    edges = np.concatenate([np.linspace(xs[i], xs[i + 1], sub + 1)[:-1] for i in range(len(xs) - 1)] + [[xs[-1]]])
+    a, b = edges[:-1], edges[1:]
+    mid, half = (a + b) / 2, (b - a) / 2
+    pts = mid[:, None] + half[:, None] * gx[None, :]
+    w = half[:, None] * gw[None, :]
+    dens = np.interp(pts, xs, ps)
+    q = qpdf(pts)
+    for k in range(1, kmax + 1):
+        mu = float((pts**k * dens * w).sum())
+        second = float(((pts**k * dens) ** 2 / q * w).sum())
+        mus.append(mu)
+        variances.append(second - mu * mu)
+    return np.array(mus), np.array(variances)
+
+
+def timed(fn, repeat):
+    best, res = None, None
+    for _ in range(repeat):
+        t0 = time.perf_counter()
+        res = fn()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return res, best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--scale", type=float, default=1.0, help="scale n_samples / n_chains down for quick runs")
+    args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    integ = MonteCarloIntegrator()
+    f1 = lambda x: x
+    f2 = lambda x: x**2
+    f3 = lambda x: x**3
+    f4 = lambda x: x**4
+    out = []
+
+    def report(name, res, truth, sigma, wall, units, unit_name):
+        err = np.abs(res.values - truth)
+        line = dict(config=name, values=res.values.tolist(), truth=np.asarray(truth).tolist(),
+                    abs_err=err.tolist(), three_sigma=(3 * np.asarray(sigma)).tolist() if sigma is not None else None,
+                    worst_err_over_3sigma=float((err / (3 * np.asarray(sigma))).max()) if sigma is not None else None,
+                    n_eff=res.meta["n_eff"], kernel_ms=res.meta["kernel_ms"], call_ms=wall * 1e3,
+                    launch=dict(n_blocks=res.meta["n_blocks"], block=res.meta["block"], lds_bytes=res.meta["lds_bytes"]),
+                    throughput_kernel=units / (res.meta["kernel_ms"] * 1e-3), throughput_call=units / wall, unit=unit_name)
+        if "accept_rate" in res.meta:
+            line["accept_rate"] = res.meta["accept_rate"]
+        out.append(line)
+        print(json.dumps(line), flush=True)
+
+    if not only or "C1" in only:
+        res, wall = timed(lambda: integ.integrate([f1, f2], Distribution.normal(0.0, 1.0), n_samples=1_000_000), args.repeat)
+        report("C1 integrate K=2 N(0,1) n=1e6", res, [0, 1], np.sqrt(np.array([1, 2]) / res.meta["n_eff"]), wall,
+               res.meta["n_eff"], "samples/s")
+    if not only or "C2" in only:
+        n = int(1e9 * args.scale)
+        res, wall = timed(lambda: integ.integrate([f1, f2, f3, f4], Distribution.normal(0.0, 1.0), n_samples=n), args.repeat)
+        report("C2 integrate K=4 N(0,1) n=1e9", res, [0, 1, 0, 3], np.sqrt(np.array([1, 2, 15, 96]) / res.meta["n_eff"]),
+               wall, res.meta["n_eff"], "samples/s")
+    if not only or "C3" in only:
+        n = int(1e9 * args.scale)
+        xs = np.linspace(0, 10, 512)
+        target = Distribution.from_pdf_table(xs, np.exp(-xs))
+        proposal = Distribution.normal(2.0, 3.0)
+        res, wall = timed(lambda: integ.integrate_importance_sampling([f1, f2, f3, f4], target, proposal, n_samples=n),
+                          args.repeat)
+        qpdf = lambda x: np.exp(-0.5 * ((x - 2.0) / 3.0) ** 2) / (3.0 * np.sqrt(2 * np.pi))
+        mu, var = table_moments(target._x_table.astype(np.float64), target._pdf_table.astype(np.float64), qpdf, 4)
+        report("C3 importance sampling K=4, 512-pt target table, N(2,3) proposal, n=1e9", res, mu,
+               np.sqrt(var / res.meta["n_eff"]), wall, res.meta["n_eff"], "samples/s")
+    if not only or "C4" in only:
+        chains = int(1_048_576 * args.scale)
+        target = Distribution.from_pdf(bimodal, support=(-10, 10))
+        proposal = Distribution.normal(0.0, 2.0)
+        res, wall = timed(lambda: integ.integrate_mcmc([f1, f2], target, proposal, n_steps=10_000, n_chains=chains,
+                                                       n_burnin=1000), max(1, args.repeat - 1))
+        steps = (res.meta["n_eff"] // 10_000) * 11_000
+        # independence sampler: integrated autocorrelation ~ (2 - a)/a with acceptance a ~ 0.66
+        tau = (2 - res.meta["accept_rate"]) / res.meta["accept_rate"]
+        # bimodal +-2 unit normals: E x^2 = 5, E x^4 = 3 + 6*4 + 16 = 43 -> var(x^2) = 18
+        sig = np.sqrt(np.array([5.0, 18.0]) * tau / res.meta["n_eff"])
+        report("C4 MCMC K=2 bimodal target, N(0,2) proposal, 1048576 chains x (1000 + 10000) steps", res, [0, 5], sig,
+               wall, steps, "MH steps/s")
+    if not only or "C5" in only:
+        n = int(1e10 * args.scale)
+        # 32 lambdas with recoverable source: a generated module
+        import importlib.util
+        import tempfile
+
+        src = "\n".join(f"f{k} = lambda x: x**{k}" for k in range(1, 33))
+        with tempfile.NamedTemporaryFile("w", suffix="_mcx_k32.py", delete=False) as fh:
+            fh.write(src + "\n")
+            path = fh.name
+        spec = importlib.util.spec_from_file_location("mcx_k32", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        fns = [getattr(mod, f"f{k}") for k in range(1, 33)]
+        dist = Distribution.beta(2.0, 5.0)
+        res, wall = timed(lambda: integ.integrate(fns, dist, n_samples=n), args.repeat)
+
+        def beta_moment(k):
+            m = 1.0
+            for j in range(k):
+                m *= (2 + j) / (7 + j)
+            return m
+
+        truth = np.array([beta_moment(k) for k in range(1, 33)])
+        var = np.array([beta_moment(2 * k) - beta_moment(k) ** 2 for k in range(1, 33)])
+        # the 2048-point CDF table has a discretisation bias of ~1e-4 relative: add it to the band
+        report("C5 integrate K=32 x^k, Beta(2,5) CDF table, n=1e10", res, truth,
+               np.sqrt(var / res.meta["n_eff"]) + truth * 2e-4 / 3, wall, res.meta["n_eff"], "samples/s")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

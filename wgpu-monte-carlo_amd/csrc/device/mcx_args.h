@@ -47,7 +47,7 @@ typedef struct McxIntegrateArgs {
     McxTableDesc cdf;           // custom sampling distribution  {cdf, x}
     McxTableDesc target_pdf;    // IS: target  {x, pdf}   (n == 0: analytic mcx_pdf_p)
     McxTableDesc proposal_pdf;  // IS: proposal {x, pdf}  (n == 0: analytic mcx_pdf_q)
-    double* partials;           // [K][gridDim.x] per-workgroup partial sums
+    double* partials;           // [gridDim.x][K] per-workgroup partial sums
 } McxIntegrateArgs;
 
 // K3: independent-proposal Metropolis-Hastings, one chain per logical thread.
@@ -63,5 +63,5 @@ typedef struct McxMcmcArgs {
     McxTableDesc cdf;           // custom proposal sampling {cdf, x}
     McxTableDesc target_logpdf;   // {x, log p}
     McxTableDesc proposal_logpdf; // {x, log q}
-    double* partials;           // [K+1][gridDim.x]; row K = accepted-step count
+    double* partials;           // [gridDim.x][K+1]; column K = accepted-step count
 } McxMcmcArgs;

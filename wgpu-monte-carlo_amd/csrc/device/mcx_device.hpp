@@ -104,7 +104,7 @@ MCX_DEV void mcx_box_muller(u32 h1, u32 h2, float& z0, float& z1) {
 #else
     // -2 ln(f1 * 2^-32) = (32 - log2 f1) * 2 ln 2, never negative
     float l2 = __builtin_amdgcn_logf(f1);
-    float r2 = fmaxf((32.0f - l2) * 0x1.62e43p+0f, 0.0f);
+    float r2 = fmaxf(fmaf(l2, -0x1.62e43p+0f, 32.0f * 0x1.62e43p+0f), 0.0f);
     float r = __builtin_amdgcn_sqrtf(r2);
     z0 = r * __builtin_amdgcn_cosf(u2);
     z1 = r * __builtin_amdgcn_sinf(u2);

@@ -84,7 +84,8 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
     return t;
 }
 
-// Fold the per-thread f64 sums of a workgroup and store row k at partials[k*gridDim.x + blockIdx.x].
+// Fold the per-thread f64 sums of a workgroup and store them as one contiguous record
+// partials[blockIdx.x * N + k] (a single N*8-byte store per workgroup).
 template <int N>
 MCX_DEV void mcx_block_reduce_store(double (&v)[N], double* partials) {
     __shared__ double red[MCX_WAVES][N];
@@ -99,7 +100,7 @@ MCX_DEV void mcx_block_reduce_store(double (&v)[N], double* partials) {
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < MCX_WAVES; ++w) s += red[w][threadIdx.x];
-        partials[(u64)threadIdx.x * gridDim.x + blockIdx.x] = s;
+        partials[(u64)blockIdx.x * N + threadIdx.x] = s;
     }
 }
 
@@ -126,6 +127,19 @@ MCX_DEV void mcx_accumulate(float x, const McxIsTables& tb, float (&acc)[MCX_K])
 #endif
 }
 
+// One sample of a non-normal distribution from one hash output.
+MCX_DEV float mcx_draw(u32 h, const McxIntegrateArgs& a, const McxTable& cdf_tb) {
+#if MCX_DIST == MCX_DIST_UNIFORM
+    (void)cdf_tb;
+    return mcx_sample_uniform(mcx_u01(h), a.param1, a.param2);
+#elif MCX_DIST == MCX_DIST_EXPONENTIAL
+    (void)cdf_tb;
+    return mcx_sample_exponential(mcx_u01_closed(h), a.param1);
+#else
+    return mcx_sample_cdf(cdf_tb, mcx_u01_closed(h));
+#endif
+}
+
 extern "C" __global__ void __launch_bounds__(MCX_BLOCK)
 mcx_integrate_kernel(McxIntegrateArgs a) {
     u32 lds_off = 0u;
@@ -136,10 +150,14 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
     (void)cdf_tb;
     __syncthreads();
 
+    // idx_count is a multiple of 64 (whole reference workgroups; checked on the host), so the 64 lanes of
+    // a wave share one chunk: the unit range [u0, u1) and every loop bound below are wave-uniform and
+    // live in SGPRs (readfirstlane makes that visible to the compiler); only `idx` differs per lane.
     const u32 g = blockIdx.x * MCX_BLOCK + threadIdx.x;
+    const u32 g_wave = __builtin_amdgcn_readfirstlane(g);
     const u32 total = a.idx_count * a.n_chunks;
-    const bool active = g < total;
-    const u32 chunk = active ? g / a.idx_count : 0u;
+    const bool active = g_wave < total;
+    const u32 chunk = active ? g_wave / a.idx_count : 0u;
     const u32 idx = a.idx_begin + (active ? g - chunk * a.idx_count : 0u);
     u32 u0 = a.unit_begin + chunk * a.units_per_chunk;
     u32 u1 = u0 + a.units_per_chunk;
@@ -150,6 +168,11 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 #pragma unroll
     for (int k = 0; k < MCX_K; ++k) sum[k] = 0.0;
 
+    // Two accumulator sets: lane A takes the first sample of every pair, lane B the second. The two
+    // evaluations of a pair are then element-wise identical instruction streams on (x0, x1) and on
+    // (accA[k], accB[k]), which the compiler packs into v_pk_mul/fma/add_f32 without register shuffles.
+    float accA[MCX_K], accB[MCX_K];
+
 #if MCX_DIST == MCX_DIST_NORMAL
     // unit = Box-Muller pair j: iterations (2j, 2j+1), counters (4j, 4j+1) (distribution.rs:97-98)
     const u32 full_pairs = a.loops_per_thread >> 1;          // pairs whose second half is used
@@ -159,20 +182,19 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
     while (j < e_full) {
         u32 blk_end = j + MCX_FLUSH;
         blk_end = blk_end < e_full ? blk_end : e_full;
-        float acc[MCX_K];
 #pragma unroll
-        for (int k = 0; k < MCX_K; ++k) acc[k] = 0.0f;
+        for (int k = 0; k < MCX_K; ++k) { accA[k] = 0.0f; accB[k] = 0.0f; }
         for (; j < blk_end; ++j) {
             u32 h1 = mcx_pcg_out(st);
             u32 h2 = mcx_pcg_out(st + MCX_STATE_STEP);
             st += 4u * MCX_STATE_STEP;
             float z0, z1;
             mcx_box_muller(h1, h2, z0, z1);
-            mcx_accumulate(a.param1 + a.param2 * z0, is_tb, acc);
-            mcx_accumulate(a.param1 + a.param2 * z1, is_tb, acc);
+            mcx_accumulate(a.param1 + a.param2 * z0, is_tb, accA);
+            mcx_accumulate(a.param1 + a.param2 * z1, is_tb, accB);
         }
 #pragma unroll
-        for (int k = 0; k < MCX_K; ++k) sum[k] += (double)acc[k];
+        for (int k = 0; k < MCX_K; ++k) sum[k] += (double)accA[k] + (double)accB[k];
     }
     if (active && u1 > full_pairs) {
         // L odd: the last pair contributes z0 only, z1 is discarded (shader_gen.rs:105-112)
@@ -181,38 +203,37 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         u32 h2 = mcx_pcg_out(st + MCX_STATE_STEP);
         float z0, z1;
         mcx_box_muller(h1, h2, z0, z1);
-        float acc[MCX_K];
 #pragma unroll
-        for (int k = 0; k < MCX_K; ++k) acc[k] = 0.0f;
-        mcx_accumulate(a.param1 + a.param2 * z0, is_tb, acc);
+        for (int k = 0; k < MCX_K; ++k) accA[k] = 0.0f;
+        mcx_accumulate(a.param1 + a.param2 * z0, is_tb, accA);
 #pragma unroll
-        for (int k = 0; k < MCX_K; ++k) sum[k] += (double)acc[k];
+        for (int k = 0; k < MCX_K; ++k) sum[k] += (double)accA[k];
     }
 #else
-    // unit = iteration i, counter i (distribution.rs:333)
+    // unit = iteration i, counter i (distribution.rs:333); two iterations per trip for the A/B lanes
     u32 st = mcx_state(a.seed, idx, u0);
     u32 i = u0;
     while (i < u1) {
-        u32 blk_end = i + MCX_FLUSH;
+        u32 blk_end = i + 2u * MCX_FLUSH;
         blk_end = blk_end < u1 ? blk_end : u1;
-        float acc[MCX_K];
 #pragma unroll
-        for (int k = 0; k < MCX_K; ++k) acc[k] = 0.0f;
-#pragma unroll 2
-        for (; i < blk_end; ++i) {
-            u32 h = mcx_pcg_out(st);
+        for (int k = 0; k < MCX_K; ++k) { accA[k] = 0.0f; accB[k] = 0.0f; }
+        for (; i + 1u < blk_end; i += 2u) {
+            u32 hA = mcx_pcg_out(st);
+            u32 hB = mcx_pcg_out(st + MCX_STATE_STEP);
+            st += 2u * MCX_STATE_STEP;
+            float xA = mcx_draw(hA, a, cdf_tb);
+            float xB = mcx_draw(hB, a, cdf_tb);
+            mcx_accumulate(xA, is_tb, accA);
+            mcx_accumulate(xB, is_tb, accB);
+        }
+        if (i < blk_end) {                                   // odd tail of the block
+            mcx_accumulate(mcx_draw(mcx_pcg_out(st), a, cdf_tb), is_tb, accA);
             st += MCX_STATE_STEP;
-#if MCX_DIST == MCX_DIST_UNIFORM
-            float x = mcx_sample_uniform(mcx_u01(h), a.param1, a.param2);
-#elif MCX_DIST == MCX_DIST_EXPONENTIAL
-            float x = mcx_sample_exponential(mcx_u01_closed(h), a.param1);
-#else
-            float x = mcx_sample_cdf(cdf_tb, mcx_u01_closed(h));
-#endif
-            mcx_accumulate(x, is_tb, acc);
+            ++i;
         }
 #pragma unroll
-        for (int k = 0; k < MCX_K; ++k) sum[k] += (double)acc[k];
+        for (int k = 0; k < MCX_K; ++k) sum[k] += (double)accA[k] + (double)accB[k];
     }
 #endif
 
@@ -342,14 +363,14 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 }
 
 // =============================================================================================
-// stage 2: fold partials[rows][n_blocks] -> out[rows] in a fixed order (one workgroup per row)
+// stage 2: fold partials[n_blocks][rows] -> out[rows] in a fixed order (one workgroup per row)
 // =============================================================================================
 extern "C" __global__ void __launch_bounds__(256)
 mcx_fold_kernel(const double* partials, u32 n_blocks, double* out) {
     __shared__ double red[4];
-    const double* row = partials + (u64)blockIdx.x * n_blocks;
+    const u32 rows = gridDim.x;
     double s = 0.0;
-    for (u32 i = threadIdx.x; i < n_blocks; i += 256u) s += row[i];
+    for (u32 i = threadIdx.x; i < n_blocks; i += 256u) s += partials[(u64)i * rows + blockIdx.x];
     s = mcx_wave_sum(s);
     if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = s;
     __syncthreads();
