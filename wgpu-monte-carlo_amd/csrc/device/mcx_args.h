@@ -18,7 +18,7 @@ typedef uint64_t mcx_u64;
 // One lookup table resident in HBM: n interleaved {key,value} float pairs.
 typedef struct McxTableDesc {
     const float* kv;        // device pointer, 2*n floats ({cdf,x} or {x,pdf})
-    const mcx_u32* guide;   // device pointer, (1<<guide_bits)+1 entries, or null
+    const mcx_u32* guide;   // device pointer, 1<<guide_bits packed windows (lo | hi<<16), or null
     mcx_u32 n;
     mcx_u32 guide_bits;
     float   inv_dk;         // (n-1)/(key[n-1]-key[0]) if the keys form a uniform grid, else 0

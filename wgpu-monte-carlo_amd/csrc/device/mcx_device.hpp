@@ -121,11 +121,21 @@ MCX_DEV void mcx_box_muller(u32 h1, u32 h2, float& z0, float& z1) {
 struct McxTable {
     const float2* kv;     // LDS or global
     u32   n;
-    float k0;             // kv[0].x
+    float k0, k1;         // kv[0].x, kv[n-1].x
     float inv_dk;         // (n-1)/(k[n-1]-k[0]) when the keys are a uniform grid, else 0
-    const u32* guide;     // CDF only: guide[b] = lower bound of b/G, (G+1) entries, or null
-    u32   guide_bits;     // G = 1 << guide_bits
+    const u32* guide;     // CDF only: guide[b] = lo | hi << 16, the search window of bucket b, or null
+    u32   guide_bits;     // number of buckets G = 1 << guide_bits
 };
+
+// a / b with v_rcp_f32 (<= 1.5 ulp): used for the interpolation weights and the importance ratio.
+// WGSL only promises 2.5 ulp for f32 division, so this stays inside the reference's own contract.
+MCX_DEV float mcx_div(float a, float b) {
+#if MCX_PRECISE_SAMPLER
+    return a / b;
+#else
+    return a * __builtin_amdgcn_rcpf(b);
+#endif
+}
 
 // First index i in [0, n-1] with key[i] >= q, searching exactly like the reference's capped loop
 // (it never tests index n-1; `cap` = 12 for CDF sampling, 16 for PDF lookup).
@@ -145,15 +155,16 @@ MCX_DEV float mcx_mix(float a, float b, float t) { return a * (1.0f - t) + b * t
 
 // sample_from_cdf_table (distribution.rs:128-158). key = cdf, value = x.
 MCX_DEV float mcx_sample_cdf(const McxTable& tb, float u) {
-    u32 n = tb.n;
+    const u32 n = tb.n;
     u32 low;
     if (tb.guide != nullptr) {
-        // bucket of u, then a short search inside [guide[b], guide[b+1]]: same index as the full
+        // bucket of u, then a short search inside the bucket's window [lo, hi]: same index as the full
         // lower bound because the table is non-decreasing (checked on the host) and n <= 4096.
-        u32 G = 1u << tb.guide_bits;
+        const u32 G = 1u << tb.guide_bits;
         u32 b = (u32)(u * (float)G);
         b = b > G - 1u ? G - 1u : b;
-        u32 lo = tb.guide[b], hi = tb.guide[b + 1u];
+        const u32 w = tb.guide[b];
+        u32 lo = w & 0xFFFFu, hi = w >> 16;
         while (lo < hi) {
             u32 mid = (lo + hi) >> 1;
             if (tb.kv[mid].x < u) lo = mid + 1u; else hi = mid;
@@ -162,45 +173,60 @@ MCX_DEV float mcx_sample_cdf(const McxTable& tb, float u) {
     } else {
         low = mcx_lower_bound_capped<12>(tb.kv, n, u);
     }
-    u32 il = (low > 1u ? low : 1u) - 1u;
-    u32 ih = low < n - 1u ? low : n - 1u;
-    float2 a = tb.kv[il], b2 = tb.kv[ih];
-    float dc = b2.x - a.x;
-    if (dc < 1.0e-10f) return a.y;
-    float t = (u - a.x) / dc;
-    return mcx_mix(a.y, b2.y, t);
+    const u32 il = (low > 1u ? low : 1u) - 1u;
+    const u32 ih = low < n - 1u ? low : n - 1u;
+    const float2 a = tb.kv[il], b2 = tb.kv[ih];
+    const float dc = b2.x - a.x;
+    const float t = mcx_div(u - a.x, dc);
+    return dc < 1.0e-10f ? a.y : mcx_mix(a.y, b2.y, t);
 }
 
 // pdf_*_from_table / log_pdf_*_from_table (distribution.rs:181-223, 375-417). key = x, value = pdf.
 // `outside` is 0.0 for PDF tables and -100.0 for log-PDF tables.
-MCX_DEV float mcx_table_lookup(const McxTable& tb, float x, float outside) {
-    u32 n = tb.n;
-    const float2* kv = tb.kv;
-    float x_min = tb.k0, x_max = kv[n - 1u].x;
-    if ((x < x_min) || (x > x_max)) return outside;
-    u32 low;
-    float2 a, b;
-    bool have = false;
-    if (tb.inv_dk != 0.0f) {
-        // uniform grid: guess the cell, verify it; the verified cell is exactly the one the
-        // reference's search + clamp selects (key[low] < x <= key[low+1]).
-        int g = (int)((x - x_min) * tb.inv_dk);
-        g = g < 0 ? 0 : (g > (int)n - 2 ? (int)n - 2 : g);
-        a = kv[g]; b = kv[g + 1];
-        if (a.x < x && x <= b.x) { low = (u32)g; have = true; }
-        else if (g > 0 && kv[g - 1].x < x && x <= a.x) { low = (u32)g - 1u; b = a; a = kv[low]; have = true; }
-        else if (g + 2 < (int)n && b.x < x && x <= kv[g + 2].x) { low = (u32)g + 1u; a = b; b = kv[low + 1u]; have = true; }
+//
+// The reference's search + clamps select the cell c with key[c] < x <= key[c+1] (c = 0 when x == key[0]).
+// On a uniform grid that cell is guessed arithmetically and VERIFIED with the two keys the interpolation
+// needs anyway. A lane whose guess fails (x within float rounding of a grid key: ~5e-4 of the lanes) takes
+// the cold path: the neighbouring cells, then the reference's capped binary search (always the path on
+// non-uniform grids, inv_dk == 0). Out-of-range lanes take no branch; they are masked at the end.
+MCX_DEV float mcx_lerp_cell(float2 a, float2 b, float x) {
+    const float dx = b.x - a.x;
+    const float t = mcx_div(x - a.x, dx);
+    return dx < 1.0e-10f ? a.y : mcx_mix(a.y, b.y, t);
+}
+
+// Cold path: cell by the reference's search (guess g < 0: no guess available).
+MCX_DEV float mcx_table_lookup_cold(const float2* kv, u32 n, float x, int g) {
+    u32 low = 0xFFFFFFFFu;
+    if (g >= 0) {
+        if (g > 0 && kv[g - 1].x < x && x <= kv[g].x) low = (u32)g - 1u;
+        else if ((u32)g + 2u < n && kv[g + 1].x < x && x <= kv[g + 2].x) low = (u32)g + 1u;
     }
-    if (!have) {
+    if (low == 0xFFFFFFFFu) {
         low = mcx_lower_bound_capped<16>(kv, n, x);
         low = (low > 1u ? low : 1u) - 1u;
         low = low < n - 2u ? low : n - 2u;
-        a = kv[low]; b = kv[low + 1u];
     }
-    float dx = b.x - a.x;
-    if (dx < 1.0e-10f) return a.y;
-    float t = (x - a.x) / dx;
-    return mcx_mix(a.y, b.y, t);
+    return mcx_lerp_cell(kv[low], kv[low + 1u], x);
+}
+
+MCX_DEV float mcx_table_lookup(const McxTable& tb, float x, float outside) {
+    const float2* kv = tb.kv;
+    const u32 n = tb.n;
+    const bool out_of_range = (x < tb.k0) || (x > tb.k1);
+    float v;
+    if (tb.inv_dk != 0.0f) {                                  // wave-uniform
+        const float gf = fminf(fmaxf((x - tb.k0) * tb.inv_dk, 0.0f), (float)(n - 2u));
+        const u32 g = (u32)gf;
+        const float2 a = kv[g], b = kv[g + 1u];
+        v = mcx_lerp_cell(a, b, x);
+        const bool verified = (a.x < x) && (x <= b.x);
+        if (__builtin_expect(!verified && !out_of_range, 0)) v = mcx_table_lookup_cold(kv, n, x, (int)g);
+    } else {
+        v = outside;
+        if (!out_of_range) v = mcx_table_lookup_cold(kv, n, x, -1);
+    }
+    return out_of_range ? outside : v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -232,6 +258,11 @@ MCX_DEV float mcx_b2f(u32 v) { return (float)v; }
 // wave64 / workgroup reductions (fixed order => bit-reproducible for a fixed launch geometry)
 // ---------------------------------------------------------------------------------------------
 MCX_DEV double mcx_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+MCX_DEV float mcx_wave_sum_f32(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;

@@ -51,6 +51,18 @@
 
 #define MCX_WAVES (MCX_BLOCK / 64)
 
+// Large K: per-thread f64 sums would need 2K VGPRs (K = 32 spills). Instead every MCX_FLUSH units each
+// wave reduces its f32 accumulators with xor-shuffles and lane 0 adds the K wave totals into f64 slots in
+// LDS ("LDS-staged" reduction); the registers hold f32 accumulators only.
+#ifndef MCX_WAVE_FLUSH
+#define MCX_WAVE_FLUSH (MCX_K > 8)
+#endif
+// Two accumulator sets (one per sample of a pair) let the compiler pack the K evaluations of both samples
+// into v_pk_* without shuffles; beyond K = 16 the second set costs more registers than packing saves.
+#ifndef MCX_PAIR_LANES
+#define MCX_PAIR_LANES (MCX_K <= 16)
+#endif
+
 extern __shared__ __attribute__((aligned(16))) unsigned char mcx_lds_raw[];
 
 // Copy one table into LDS at byte offset `off` (advanced), or leave it in HBM.
@@ -62,6 +74,7 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
     t.guide = nullptr;
     t.kv = nullptr;
     t.k0 = 0.0f;
+    t.k1 = 0.0f;
     if (d.n == 0u) return t;
 #if MCX_TABLES_LDS
     float2* dst = (float2*)(mcx_lds_raw + off);
@@ -71,9 +84,9 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
     t.kv = dst;
     if (d.guide != nullptr) {
         u32* gdst = (u32*)(mcx_lds_raw + off);
-        u32 gn = (1u << d.guide_bits) + 1u;
+        u32 gn = 1u << d.guide_bits;
         for (u32 i = threadIdx.x; i < gn; i += MCX_BLOCK) gdst[i] = d.guide[i];
-        off += ((gn + 1u) & ~1u) * 4u;
+        off += gn * 4u;
         t.guide = gdst;
     }
 #else
@@ -81,6 +94,7 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
     t.guide = d.guide;
 #endif
     t.k0 = d.kv[0];
+    t.k1 = d.kv[2u * (d.n - 1u)];
     return t;
 }
 
@@ -121,7 +135,7 @@ MCX_DEV void mcx_accumulate(float x, const McxIsTables& tb, float (&acc)[MCX_K])
 #else
     float q = mcx_b2f(mcx_pdf_q(x));
 #endif
-    mcx_eval_all(x, p / q, acc);
+    mcx_eval_all(x, mcx_div(p, q), acc);
 #else
     mcx_eval_all(x, 1.0f, acc);
 #endif
@@ -164,14 +178,42 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
     u1 = u1 < a.unit_end ? u1 : a.unit_end;
     if (!active) { u0 = 0u; u1 = 0u; }
 
-    double sum[MCX_K];
-#pragma unroll
-    for (int k = 0; k < MCX_K; ++k) sum[k] = 0.0;
-
     // Two accumulator sets: lane A takes the first sample of every pair, lane B the second. The two
     // evaluations of a pair are then element-wise identical instruction streams on (x0, x1) and on
     // (accA[k], accB[k]), which the compiler packs into v_pk_mul/fma/add_f32 without register shuffles.
-    float accA[MCX_K], accB[MCX_K];
+    float accA[MCX_K];
+#if MCX_PAIR_LANES
+    float accB[MCX_K];
+#define MCX_ACC_B accB
+#else
+#define MCX_ACC_B accA
+#endif
+
+#if MCX_WAVE_FLUSH
+    __shared__ double wave_sums[MCX_WAVES][MCX_K];
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane < (u32)MCX_K) wave_sums[wave][lane] = 0.0;
+#define MCX_FLUSH_ACC()                                                                     \
+    do {                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < MCX_K; ++k) {                                 \
+            float s_ = mcx_wave_sum_f32(MCX_PAIR_LANES ? accA[k] + MCX_ACC_B[k] : accA[k]); \
+            if (lane == 0u) wave_sums[wave][k] += (double)s_;                               \
+        }                                                                                   \
+    } while (0)
+#else
+    double sum[MCX_K];
+#pragma unroll
+    for (int k = 0; k < MCX_K; ++k) sum[k] = 0.0;
+#define MCX_FLUSH_ACC()                                                                     \
+    do {                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < MCX_K; ++k)                                   \
+            sum[k] += MCX_PAIR_LANES ? (double)accA[k] + (double)MCX_ACC_B[k] : (double)accA[k]; \
+    } while (0)
+#endif
+#define MCX_ZERO_ACC()                                                                      \
+    do {                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < MCX_K; ++k) { accA[k] = 0.0f; MCX_ACC_B[k] = 0.0f; } \
+    } while (0)
 
 #if MCX_DIST == MCX_DIST_NORMAL
     // unit = Box-Muller pair j: iterations (2j, 2j+1), counters (4j, 4j+1) (distribution.rs:97-98)
@@ -182,8 +224,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
     while (j < e_full) {
         u32 blk_end = j + MCX_FLUSH;
         blk_end = blk_end < e_full ? blk_end : e_full;
-#pragma unroll
-        for (int k = 0; k < MCX_K; ++k) { accA[k] = 0.0f; accB[k] = 0.0f; }
+        MCX_ZERO_ACC();
         for (; j < blk_end; ++j) {
             u32 h1 = mcx_pcg_out(st);
             u32 h2 = mcx_pcg_out(st + MCX_STATE_STEP);
@@ -191,10 +232,9 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
             float z0, z1;
             mcx_box_muller(h1, h2, z0, z1);
             mcx_accumulate(a.param1 + a.param2 * z0, is_tb, accA);
-            mcx_accumulate(a.param1 + a.param2 * z1, is_tb, accB);
+            mcx_accumulate(a.param1 + a.param2 * z1, is_tb, MCX_ACC_B);
         }
-#pragma unroll
-        for (int k = 0; k < MCX_K; ++k) sum[k] += (double)accA[k] + (double)accB[k];
+        MCX_FLUSH_ACC();
     }
     if (active && u1 > full_pairs) {
         // L odd: the last pair contributes z0 only, z1 is discarded (shader_gen.rs:105-112)
@@ -203,11 +243,9 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         u32 h2 = mcx_pcg_out(st + MCX_STATE_STEP);
         float z0, z1;
         mcx_box_muller(h1, h2, z0, z1);
-#pragma unroll
-        for (int k = 0; k < MCX_K; ++k) accA[k] = 0.0f;
+        MCX_ZERO_ACC();
         mcx_accumulate(a.param1 + a.param2 * z0, is_tb, accA);
-#pragma unroll
-        for (int k = 0; k < MCX_K; ++k) sum[k] += (double)accA[k];
+        MCX_FLUSH_ACC();
     }
 #else
     // unit = iteration i, counter i (distribution.rs:333); two iterations per trip for the A/B lanes
@@ -216,8 +254,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
     while (i < u1) {
         u32 blk_end = i + 2u * MCX_FLUSH;
         blk_end = blk_end < u1 ? blk_end : u1;
-#pragma unroll
-        for (int k = 0; k < MCX_K; ++k) { accA[k] = 0.0f; accB[k] = 0.0f; }
+        MCX_ZERO_ACC();
         for (; i + 1u < blk_end; i += 2u) {
             u32 hA = mcx_pcg_out(st);
             u32 hB = mcx_pcg_out(st + MCX_STATE_STEP);
@@ -225,19 +262,31 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
             float xA = mcx_draw(hA, a, cdf_tb);
             float xB = mcx_draw(hB, a, cdf_tb);
             mcx_accumulate(xA, is_tb, accA);
-            mcx_accumulate(xB, is_tb, accB);
+            mcx_accumulate(xB, is_tb, MCX_ACC_B);
         }
         if (i < blk_end) {                                   // odd tail of the block
             mcx_accumulate(mcx_draw(mcx_pcg_out(st), a, cdf_tb), is_tb, accA);
             st += MCX_STATE_STEP;
             ++i;
         }
-#pragma unroll
-        for (int k = 0; k < MCX_K; ++k) sum[k] += (double)accA[k] + (double)accB[k];
+        MCX_FLUSH_ACC();
     }
 #endif
 
+#if MCX_WAVE_FLUSH
+    __syncthreads();
+    if (threadIdx.x < (u32)MCX_K) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < MCX_WAVES; ++w) s += wave_sums[w][threadIdx.x];
+        a.partials[(u64)blockIdx.x * MCX_K + threadIdx.x] = s;
+    }
+#else
     mcx_block_reduce_store<MCX_K>(sum, a.partials);
+#endif
+#undef MCX_FLUSH_ACC
+#undef MCX_ZERO_ACC
+#undef MCX_ACC_B
 }
 
 // =============================================================================================
@@ -250,6 +299,19 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 #define MCX_ACCEPT_SEED_OFFSET 999999u     // shader_gen.rs:529
 #endif
 
+// One proposal of a non-normal family from one hash output.
+MCX_DEV float mcx_draw_proposal(u32 h, const McxMcmcArgs& a, const McxTable& cdf_tb) {
+#if MCX_DIST == MCX_DIST_UNIFORM
+    (void)cdf_tb;
+    return mcx_sample_uniform(mcx_u01(h), a.param1, a.param2);
+#elif MCX_DIST == MCX_DIST_EXPONENTIAL
+    (void)cdf_tb;
+    return mcx_sample_exponential(mcx_u01_closed(h), a.param1);
+#else
+    return mcx_sample_cdf(cdf_tb, mcx_u01_closed(h));
+#endif
+}
+
 extern "C" __global__ void __launch_bounds__(MCX_BLOCK)
 mcx_mcmc_kernel(McxMcmcArgs a) {
     u32 lds_off = 0u;
@@ -259,10 +321,11 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     (void)cdf_tb;
     __syncthreads();
 
+    // chain_count is a multiple of 256, so a wave is entirely inside or outside the launch's chain range
     const u32 g = blockIdx.x * MCX_BLOCK + threadIdx.x;
-    const bool active = g < a.chain_count;
+    const bool active = __builtin_amdgcn_readfirstlane(g) < a.chain_count;
     const u32 idx = a.chain_begin + (active ? g : 0u);
-    const u32 total_steps = active ? a.n_burnin + a.n_steps : 0u;
+    const u32 total_steps = active ? a.n_burnin + a.n_steps : 0u;     // wave-uniform
 
     double sum[MCX_K + 1];
 #pragma unroll
@@ -286,67 +349,31 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     // proposal state for even `it`: counters 2*(it+OFFSET), 2*(it+OFFSET)+1
     u32 st_prop = mcx_state(a.seed, idx, 2u * (2u + MCX_PROP_ITER_OFFSET));
 #else
-    {
-        u32 h = mcx_pcg_out(mcx_state(a.seed, idx, 0u));
-#if MCX_DIST == MCX_DIST_UNIFORM
-        cur_x = mcx_sample_uniform(mcx_u01(h), a.param1, a.param2);
-#elif MCX_DIST == MCX_DIST_EXPONENTIAL
-        cur_x = mcx_sample_exponential(mcx_u01_closed(h), a.param1);
-#else
-        cur_x = mcx_sample_cdf(cdf_tb, mcx_u01_closed(h));
-#endif
-    }
+    cur_x = mcx_draw_proposal(mcx_pcg_out(mcx_state(a.seed, idx, 0u)), a, cdf_tb);
     u32 st_prop = mcx_state(a.seed, idx, 1u + MCX_PROP_ITER_OFFSET);
 #endif
     float cur_lp = mcx_table_lookup(lp_tb, cur_x, -100.0f);
     float cur_lq = mcx_table_lookup(lq_tb, cur_x, -100.0f);   // pure function of cur_x: cached
     u32 st_acc = mcx_state(a.seed + MCX_ACCEPT_SEED_OFFSET, idx, 1u);
 
-    for (u32 it = 1u; it <= total_steps; ++it) {
-        // ---- proposal x' ~ q with counter it + OFFSET ----
-        float prop_x;
-#if MCX_DIST == MCX_DIST_NORMAL
-        if (it & 1u) {
-            prop_x = a.param1 + a.param2 * z_cached;           // second half of the previous pair
-        } else {
-            float z0;
-            mcx_box_muller(mcx_pcg_out(st_prop), mcx_pcg_out(st_prop + MCX_STATE_STEP), z0, z_cached);
-            st_prop += 4u * MCX_STATE_STEP;                    // next even `it` is it + 2
-            prop_x = a.param1 + a.param2 * z0;
-        }
-#else
-        {
-            u32 h = mcx_pcg_out(st_prop);
-            st_prop += MCX_STATE_STEP;
-#if MCX_DIST == MCX_DIST_UNIFORM
-            prop_x = mcx_sample_uniform(mcx_u01(h), a.param1, a.param2);
-#elif MCX_DIST == MCX_DIST_EXPONENTIAL
-            prop_x = mcx_sample_exponential(mcx_u01_closed(h), a.param1);
-#else
-            prop_x = mcx_sample_cdf(cdf_tb, mcx_u01_closed(h));
-#endif
-        }
-#endif
-        // ---- MH ratio (shader_gen.rs:518-526) ----
+    // One Metropolis-Hastings step with proposal prop_x (shader_gen.rs:511-537); `it` is wave-uniform.
+    auto mh_step = [&](u32 it, float prop_x) {
         float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
         float prop_lq = mcx_table_lookup(lq_tb, prop_x, -100.0f);
-        float log_alpha = prop_lp + cur_lq - cur_lp - prop_lq;
-        // ---- accept: log(U(seed+999999, idx, it)) < log_alpha (shader_gen.rs:529-534) ----
-        u32 ha = mcx_pcg_out(st_acc);
+        float log_alpha = prop_lp + cur_lq - cur_lp - prop_lq;                     // shader_gen.rs:526
+        u32 ha = mcx_pcg_out(st_acc);                                              // U(seed+999999, idx, it)
         st_acc += MCX_STATE_STEP;
 #if MCX_PRECISE_SAMPLER
         float ln_u = logf(mcx_u01_closed(ha));
 #else
-        float ln_u = (__builtin_amdgcn_logf((float)ha) - 32.0f) * 0x1.62e43p-1f;   // h = 0 -> -inf
+        float ln_u = (__builtin_amdgcn_logf((float)ha) - 32.0f) * 0x1.62e43p-1f;   // h = 0 -> -inf: accept
 #endif
-        if (ln_u < log_alpha) {
-            cur_x = prop_x;
-            cur_lp = prop_lp;
-            cur_lq = prop_lq;
-            ++n_accept;
-        }
-        // ---- accumulate after every sampling step, accepted or not (shader_gen.rs:417-423) ----
-        if (it > a.n_burnin) {
+        const bool take = ln_u < log_alpha;
+        cur_x = take ? prop_x : cur_x;
+        cur_lp = take ? prop_lp : cur_lp;
+        cur_lq = take ? prop_lq : cur_lq;
+        n_accept += take ? 1u : 0u;
+        if (it > a.n_burnin) {                   // accumulate after every sampling step (shader_gen.rs:417-423)
             mcx_eval_all(cur_x, 1.0f, acc);
             if (++since_flush == 2u * MCX_FLUSH) {
 #pragma unroll
@@ -354,7 +381,32 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
                 since_flush = 0u;
             }
         }
+    };
+
+#if MCX_DIST == MCX_DIST_NORMAL
+    // odd `it` consumes the z1 cached by the previous draw (it = 1: the initial draw's), even `it` draws a
+    // new pair from counters 2*(it+OFFSET), +1 (distribution.rs:90-114 through shader_gen.rs:481)
+    u32 it = 1u;
+    if (total_steps >= 1u) { mh_step(1u, a.param1 + a.param2 * z_cached); it = 2u; }
+    for (; it + 1u <= total_steps; it += 2u) {
+        float z0, z1;
+        mcx_box_muller(mcx_pcg_out(st_prop), mcx_pcg_out(st_prop + MCX_STATE_STEP), z0, z1);
+        st_prop += 4u * MCX_STATE_STEP;
+        mh_step(it, a.param1 + a.param2 * z0);
+        mh_step(it + 1u, a.param1 + a.param2 * z1);
     }
+    if (it <= total_steps && it >= 2u) {
+        float z0, z1;
+        mcx_box_muller(mcx_pcg_out(st_prop), mcx_pcg_out(st_prop + MCX_STATE_STEP), z0, z1);
+        mh_step(it, a.param1 + a.param2 * z0);
+    }
+#else
+    for (u32 it = 1u; it <= total_steps; ++it) {
+        u32 h = mcx_pcg_out(st_prop);
+        st_prop += MCX_STATE_STEP;
+        mh_step(it, mcx_draw_proposal(h, a, cdf_tb));
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < MCX_K; ++k) sum[k] += (double)acc[k];
     sum[MCX_K] = (double)n_accept;

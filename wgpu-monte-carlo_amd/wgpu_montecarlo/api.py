@@ -64,12 +64,12 @@ def _check_count(value, name: str, bits: int = 64) -> int:
     return int(value)
 
 
-def functions_to_hip(functions: Sequence[FunctionLike], fast_math: bool = False) -> str:
+def functions_to_hip(functions: Sequence[FunctionLike], math="default") -> str:
     """Emit `user_func_0 .. user_func_{K-1}` (HIP C++) for callables and raw WGSL strings."""
     parts = [emit_hip.prelude()]
     for i, fn in enumerate(functions):
         if callable(fn):
-            parts.append(emit_hip.emit_function(frontend.lower(fn), f"user_func_{i}", fast_math))
+            parts.append(emit_hip.emit_function(frontend.lower(fn), f"user_func_{i}", math))
         elif isinstance(fn, str):
             parts.append(wgsl_to_hip.translate(fn, i, f"user_func_{i}"))
         else:
@@ -77,11 +77,11 @@ def functions_to_hip(functions: Sequence[FunctionLike], fast_math: bool = False)
     return "\n\n".join(parts)
 
 
-def _pdf_to_hip(dist: Distribution, name: str, fast_math: bool) -> Optional[str]:
+def _pdf_to_hip(dist: Distribution, name: str, math="default") -> Optional[str]:
     """HIP text of a distribution's PDF closure, or None when it is outside the emitter's subset
     (the reference's table-vs-analytic decision, __init__.py:825-838)."""
     try:
-        return emit_hip.emit_function(frontend.lower(dist._pdf_func), name, fast_math)
+        return emit_hip.emit_function(frontend.lower(dist._pdf_func), name, math)
     except TranspilerError:
         return None
 
@@ -116,7 +116,8 @@ class MonteCarloIntegrator:
         device: HIP device index (default: LOCAL_RANK if set, else 0).
         process_group: torch.distributed group to shard over; default = the world group when
             torch.distributed is initialised, else single GPU.
-        math: "default" (ocml functions in user code) or "fast" (hardware sin/cos/exp/log).
+        math: "default" (hardware exp/log/sqrt/rcp within WGSL's accuracy contract, ocml sin/cos/pow),
+            "fast" (also hardware sin/cos/tan) or "precise" (ocml + IEEE division everywhere).
         strict_reference_uniform: reproduce u = float(hash)*2^-32 on the closed interval [0,1]
             (reference behaviour, can produce log(0)); default False guards the end points.
     """
@@ -134,7 +135,7 @@ class MonteCarloIntegrator:
         self._engine = runtime.Engine(device)       # RuntimeError("Failed to initialize GPU: ...") without a GPU
         self._integrator = self._engine             # attribute name the reference uses for its native object
         self._target_threads = target_threads
-        self._fast_math = math == "fast"
+        self._math = math
         self._precise_sampler = math == "precise"
         self._guard = not strict_reference_uniform
         self._group = distributed.Group(process_group) if process_group is not None else distributed.default_group()
@@ -169,7 +170,7 @@ class MonteCarloIntegrator:
             total += tb.n * 8
             bits = tb.info()["guide_bits"]
             if bits:
-                total += (((1 << bits) + 2) & ~1) * 4
+                total += (1 << bits) * 4
         return total
 
     def _run(self, rows: int, call):
@@ -204,7 +205,7 @@ class MonteCarloIntegrator:
         """E[f_k(X)], X ~ distribution, for all functions on the same samples."""
         if len(functions) == 0:
             raise ValueError("At least one function is required")
-        user_src = functions_to_hip(functions, self._fast_math)
+        user_src = functions_to_hip(functions, self._math)
         n_samples = _check_count(n_samples, "n_samples")
         seed = _check_seed(seed)
         code, p1, p2 = _dist_params(distribution)
@@ -226,9 +227,9 @@ class MonteCarloIntegrator:
         """E_p[f_k(X)] ~= mean f_k(x) p(x)/q(x), x ~ q."""
         if len(functions) == 0:
             raise ValueError("At least one function is required")
-        p_src = _pdf_to_hip(target_distribution, "mcx_pdf_p", self._fast_math)
-        q_src = _pdf_to_hip(proposal_distribution, "mcx_pdf_q", self._fast_math)
-        user_src = functions_to_hip(functions, self._fast_math)
+        p_src = _pdf_to_hip(target_distribution, "mcx_pdf_p", self._math)
+        q_src = _pdf_to_hip(proposal_distribution, "mcx_pdf_q", self._math)
+        user_src = functions_to_hip(functions, self._math)
         n_samples = _check_count(n_samples, "n_samples")
         seed = _check_seed(seed)
         code, p1, p2 = _dist_params(proposal_distribution)
@@ -269,7 +270,7 @@ class MonteCarloIntegrator:
             raise ValueError("n_chains must be positive")
         if n_burnin < 0:
             raise ValueError("n_burnin must be non-negative")
-        user_src = functions_to_hip(functions, self._fast_math)
+        user_src = functions_to_hip(functions, self._math)
         n_steps = _check_count(n_steps, "n_steps", 32)
         n_chains = _check_count(n_chains, "n_chains", 32)
         n_burnin = _check_count(n_burnin, "n_burnin", 32)
@@ -302,7 +303,7 @@ class MonteCarloIntegrator:
         reference re-transpiles and re-compiles (src/engine.rs:325-331)."""
         if len(functions) == 0:
             raise ValueError("At least one function is required")
-        user_src = functions_to_hip(functions, self._fast_math)
+        user_src = functions_to_hip(functions, self._math)
         code, p1, p2 = _dist_params(distribution)
         cdf = self._cdf_table(distribution)
         lds_ok = self._lds_bytes(cdf) <= _LDS_TABLE_BUDGET

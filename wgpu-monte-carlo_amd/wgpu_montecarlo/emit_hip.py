@@ -45,12 +45,20 @@ _FUNCS = {
 }
 _ARITY = {"min": 2, "max": 2, "clamp": 3, "mix": 3, "step": 2, "smoothstep": 3, "pow": 2, "power": 2}
 
-# hardware-instruction variants selected by math="fast"
-_FAST_FUNCS = {
-    "sin": "__sinf({0})", "cos": "__cosf({0})", "exp": "__expf({0})", "exp2": "__builtin_amdgcn_exp2f({0})",
-    "log": "__logf({0})", "log2": "__builtin_amdgcn_logf({0})", "sqrt": "__builtin_amdgcn_sqrtf({0})",
-    "tan": "__tanf({0})",
+# math modes (MonteCarloIntegrator(math=...)):
+#   "precise": ocml functions and IEEE division everywhere.
+#   "default": exp / log / sqrt / division use the hardware instructions (v_exp_f32, v_log_f32, v_sqrt_f32,
+#              v_rcp_f32: 1-2 ulp, exp degrading like 2|x| ulp). That is inside the accuracy WGSL itself
+#              promises for these operations (division 2.5 ulp, exp 3 + 2|x| ulp, log 3 ulp, sqrt via
+#              inverseSqrt 2 ulp), i.e. inside what the reference's own backends deliver. sin / cos / tan /
+#              pow keep the ocml versions because their hardware forms are only valid on a bounded domain.
+#   "fast":    additionally __sinf / __cosf / __tanf (argument range |x| < ~1600).
+_NATIVE_FUNCS = {
+    "exp": "__expf({0})", "exp2": "__builtin_amdgcn_exp2f({0})", "log": "__logf({0})",
+    "log2": "__builtin_amdgcn_logf({0})", "sqrt": "__builtin_amdgcn_sqrtf({0})",
 }
+_FAST_FUNCS = dict(_NATIVE_FUNCS, sin="__sinf({0})", cos="__cosf({0})", tan="__tanf({0})")
+MATH_MODES = ("precise", "default", "fast")
 
 _CONST_VALUES = {
     "pi": math.pi, "e": math.e, "tau": math.tau, "euler_gamma": 0.5772156649015329,
@@ -84,9 +92,20 @@ def float_literal(value: float) -> str:
     return text + "f"
 
 
+def _mode(math) -> str:
+    if math is True:
+        return "fast"
+    if math is False or math is None:
+        return "default"
+    if math not in MATH_MODES:
+        raise ValueError(f"math must be one of {MATH_MODES}")
+    return math
+
+
 class _HipPrinter:
-    def __init__(self, fast_math: bool) -> None:
-        self.fast = fast_math
+    def __init__(self, math) -> None:
+        self.mode = _mode(math)
+        self.table = {"precise": {}, "default": _NATIVE_FUNCS, "fast": _FAST_FUNCS}[self.mode]
 
     def expr(self, node) -> str:
         if isinstance(node, ir.Num):
@@ -101,6 +120,8 @@ class _HipPrinter:
             left, right = self.expr(node.left), self.expr(node.right)
             if node.op == "%":
                 return f"fmodf({left}, {right})"
+            if node.op == "/" and self.mode != "precise":
+                return f"mcx_div({left}, {right})"
             return f"({left} {node.op} {right})"
         if isinstance(node, ir.Pow):
             base = self.expr(node.base)
@@ -111,7 +132,9 @@ class _HipPrinter:
             if isinstance(exponent, ir.Num) and float(exponent.value).is_integer() and 0 <= exponent.value <= 64:
                 n = int(exponent.value)
                 chain = f"McxPowI<{n}>::of({base})"
-                return chain if sign > 0 else f"(1.0f / {chain})"
+                if sign > 0:
+                    return chain
+                return f"(1.0f / {chain})" if self.mode == "precise" else f"mcx_div(1.0f, {chain})"
             return f"powf({base}, {self.expr(node.exponent)})"
         if isinstance(node, ir.Unary):
             return f"({node.op}{self.expr(node.operand)})"
@@ -122,7 +145,7 @@ class _HipPrinter:
         if isinstance(node, ir.Select):
             return f"(({self.expr(node.test)}) ? mcx_b2f({self.expr(node.body)}) : mcx_b2f({self.expr(node.orelse)}))"
         if isinstance(node, ir.Call):
-            template = (_FAST_FUNCS.get(node.name) if self.fast else None) or _FUNCS.get(node.name)
+            template = self.table.get(node.name) or _FUNCS.get(node.name)
             if template is None:
                 raise TranspilerError(
                     f"Unsupported function call: {node.name}. Supported functions: {', '.join(sorted(_FUNCS))}"
@@ -173,9 +196,9 @@ def _assigned_names(stmts, acc: List[str]) -> None:
             _assigned_names(st.body, acc)
 
 
-def emit_function(fn: ir.Function, name: str, fast_math: bool = False) -> str:
-    """One IR function as a HIP device function called `name`."""
-    printer = _HipPrinter(fast_math)
+def emit_function(fn: ir.Function, name: str, math="default") -> str:
+    """One IR function as a HIP device function called `name` (math: "precise" | "default" | "fast")."""
+    printer = _HipPrinter(math)
     params = ", ".join(f"float {_ident(p)}" for p in fn.params)
     lines = [f"MCX_DEV float {name}({params}) {{"]
     for cname, cvalue in fn.consts.items():

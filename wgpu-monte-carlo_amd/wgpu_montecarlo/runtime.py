@@ -162,6 +162,8 @@ def shard_chains(total_chains: int, rank: int, world: int):
 def make_desc(kind: int, k: int, dist_type: int, weight: bool = False, p_table: bool = False,
               q_table: bool = False, guard_endpoints: bool = True, precise_sampler: bool = False,
               block: int = 0, tables_lds: bool = True) -> ModuleDesc:
+    if not block and os.environ.get("MCX_BLOCK"):        # tuning knob
+        block = int(os.environ["MCX_BLOCK"])
     return ModuleDesc(kind, k, dist_type, int(weight), int(p_table), int(q_table), int(guard_endpoints),
                       int(precise_sampler), int(block), int(tables_lds))
 

@@ -17,11 +17,11 @@ class PythonToWGSL:
 class PythonToHIP:
     """Python callable -> HIP C++ device function (what the MI355X kernels are built from)."""
 
-    def __init__(self, fast_math: bool = False):
-        self.fast_math = fast_math
+    def __init__(self, math="default"):
+        self.math = math
 
     def transpile(self, func: Callable, name: str = "user_func_0") -> str:
-        return emit_hip.emit_function(frontend.lower(func), name, self.fast_math)
+        return emit_hip.emit_function(frontend.lower(func), name, self.math)
 
 
 def transpile_function(func: Callable) -> str:
@@ -29,6 +29,6 @@ def transpile_function(func: Callable) -> str:
     return PythonToWGSL().transpile(func)
 
 
-def transpile_function_hip(func: Callable, name: str = "user_func_0", fast_math: bool = False) -> str:
-    """HIP C++ text of `func`."""
-    return PythonToHIP(fast_math).transpile(func, name)
+def transpile_function_hip(func: Callable, name: str = "user_func_0", math="default", fast_math: bool = False) -> str:
+    """HIP C++ text of `func` (math: "precise" | "default" | "fast")."""
+    return PythonToHIP("fast" if fast_math else math).transpile(func, name)
