@@ -1,0 +1,193 @@
+"""Public-API behaviour on the GPU, scenario by scenario as the reference's own GPU tests exercise it
+(tests/test_integrator.py, test_distributions.py, test_importance_sampling.py, test_mcmc.py in the
+reference; cited per test). Accuracy bars are the reference's: |E - truth| < 0.01 at n = 1e7 etc.
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mc(integrator):
+    return integrator
+
+
+def D():
+    from wgpu_montecarlo import Distribution
+
+    return Distribution
+
+
+# ---- tests/test_integrator.py ------------------------------------------------------------------
+def test_result_object_shape(mc):                                      # :24-46, :293-357
+    res = mc.integrate([lambda x: x, lambda x: x**2, lambda x: x**3], D().normal(0.0, 1.0), n_samples=1_000_000, seed=42)
+    assert len(res) == 3 and res.n_functions == 3 and res.n_samples == 1_000_000
+    assert res.values.dtype == np.float64 and res.values.shape == (3,)
+    assert res[1] == res.values[1]
+    assert "IntegrationResult" in repr(res)
+    assert abs(res.values[0]) < 0.1 and abs(res.values[1] - 1.0) < 0.1 and abs(res.values[2]) < 0.1
+
+
+def test_lambdas_written_inline_and_unpacked(mc):                      # :92-160
+    res = mc.integrate(
+        [lambda x: x, lambda x: x**2, lambda x: x**3, lambda x: x**4],
+        D().normal(0.0, 1.0),
+        n_samples=1_000_000,
+        seed=42,
+    )
+    assert np.all(np.abs(res.values - [0, 1, 0, 3]) < 0.1)
+    f1, f2 = lambda x: x, lambda x: x**2
+    res = mc.integrate([f1, f2], D().normal(0.0, 1.0), n_samples=1_000_000, seed=42)
+    assert abs(res.values[0]) < 0.1 and abs(res.values[1] - 1.0) < 0.1
+
+
+def test_named_functions_closures_and_globals(mc):                     # :259-307
+    scale = 2.0
+
+    def scaled_square(x):
+        y = x * scale
+        return y * y
+
+    def indicator(x):
+        if x > 0.0:
+            return 1.0
+        return 0.0
+
+    res = mc.integrate([scaled_square, indicator, lambda x: np.abs(x)], D().normal(0.0, 1.0), n_samples=2_000_000)
+    assert abs(res.values[0] - 4.0) < 0.05 and abs(res.values[1] - 0.5) < 0.01
+    assert abs(res.values[2] - math.sqrt(2 / math.pi)) < 0.01
+
+
+
+def test_accuracy_at_1e7(mc):                                          # :165-257
+    n = 10_000_000
+    r = mc.integrate([lambda x: x, lambda x: x**2], D().normal(0.0, 1.0), n_samples=n)
+    assert abs(r.values[0]) < 0.01 and abs(r.values[1] - 1.0) < 0.01
+    r = mc.integrate([lambda x: x, lambda x: x**2], D().uniform(0.0, 1.0), n_samples=n)
+    assert abs(r.values[0] - 0.5) < 0.01 and abs(r.values[1] - 1 / 3) < 0.01
+    r = mc.integrate([lambda x: x, lambda x: x**2], D().exponential(2.0), n_samples=n)
+    assert abs(r.values[0] - 0.5) < 0.01 and abs(r.values[1] - 0.5) < 0.01
+    r = mc.integrate([lambda x: math.sin(x), lambda x: math.cos(x)], D().uniform(0.0, 2 * math.pi), n_samples=n)
+    assert abs(r.values[0]) < 0.01 and abs(r.values[1]) < 0.01
+    r = mc.integrate([lambda x: x, lambda x: (x - 5.0) ** 2], D().normal(5.0, 2.0), n_samples=n)
+    assert abs(r.values[0] - 5.0) < 0.01 and abs(r.values[1] - 4.0) < 0.02
+
+
+def test_convenience_function_and_target_threads():                    # :309-357; test_importance_sampling.py:414-428
+    from wgpu_montecarlo import integrate
+
+    a = integrate([lambda x: x**2], D().normal(0.0, 1.0), n_samples=1_000_000, seed=7)
+    b = integrate([lambda x: x**2], D().normal(0.0, 1.0), n_samples=1_000_000, seed=7, target_threads=32768)
+    assert a.meta["n_eff"] == 65536 * 16 and b.meta["n_eff"] == 32768 * 31
+    assert abs(a.values[0] - 1.0) < 0.01 and abs(b.values[0] - 1.0) < 0.01
+    assert a.values[0] != b.values[0]                     # T changes the sample indexing, as in the reference
+
+
+# ---- tests/test_distributions.py -----------------------------------------------------------------
+def test_beta_moments_and_table_vs_direct(mc):                         # :78-157
+    r = mc.integrate([lambda x: x, lambda x: x**2, lambda x: x**3], D().beta(2.0, 5.0), n_samples=10_000_000)
+    assert np.all(np.abs(r.values - [2 / 7, 3 / 28, 1 / 21]) < 0.01)
+    table_u = D().from_pdf(lambda x: 1.0 if 0 <= x <= 1 else 0.0, support=(0.0, 1.0))
+    a = mc.integrate([lambda x: x, lambda x: x**2], table_u, n_samples=5_000_000)
+    b = mc.integrate([lambda x: x, lambda x: x**2], D().uniform(0.0, 1.0), n_samples=5_000_000)
+    assert np.all(np.abs(a.values - b.values) < 0.01)
+    small = D().beta(2.0, 2.0, table_size=100)                          # :351-360 minimum 1000 points
+    assert small.params["table_size"] == 1000
+    r = mc.integrate([lambda x: x], small, n_samples=2_000_000)
+    assert abs(r.values[0] - 0.5) < 0.01
+
+
+# ---- tests/test_importance_sampling.py -----------------------------------------------------------
+def test_importance_sampling_cases(mc):                                # :34-131
+    fns = [lambda x: x, lambda x: x**2, lambda x: x**4]
+    r = mc.integrate_importance_sampling(fns, D().normal(0.0, 1.0), D().normal(0.5, 1.5), n_samples=5_000_000)
+    assert abs(r.values[0]) < 0.05 and abs(r.values[1] - 1.0) < 0.05 and abs(r.values[2] - 3.0) < 0.3
+    r = mc.integrate_importance_sampling([lambda x: x], D().exponential(1.0), D().exponential(0.5), n_samples=5_000_000)
+    assert abs(r.values[0] - 1.0) < 0.05
+    r = mc.integrate_importance_sampling([lambda x: x, lambda x: x**2], D().uniform(0.0, 1.0), D().uniform(-0.5, 1.5),
+                                         n_samples=5_000_000)
+    assert abs(r.values[0] - 0.5) < 0.05 and abs(r.values[1] - 1 / 3) < 0.05
+    # rare-event tail probability P(X > 3), X ~ N(0,1), proposal centred on the tail
+    r = mc.integrate_importance_sampling([lambda x: x > 3.0], D().normal(0.0, 1.0), D().normal(3.5, 1.0),
+                                         n_samples=5_000_000)
+    assert abs(r.values[0] - 0.0013499) < 2e-5
+
+
+def test_importance_sampling_custom_pdfs(mc):                          # :155-363
+    def tri(x):                                                         # transpilable: if / return body
+        if x < 0.0:
+            return 0.0
+        if x > 1.0:
+            return 0.0
+        return 2.0 * x
+
+    target = D().from_pdf(tri, support=(0.0, 1.0))
+    r = mc.integrate_importance_sampling([lambda x: x], target, D().uniform(0.0, 1.0), n_samples=5_000_000)
+    assert abs(r.values[0] - 2 / 3) < 0.01
+
+    def not_transpilable(x):                                            # int() -> table path (reference :291-299)
+        return float(int(0.0 <= x <= 1.0)) * 2.0 * x
+
+    r = mc.integrate_importance_sampling([lambda x: x], D().from_pdf(not_transpilable, support=(0.0, 1.0)),
+                                         D().uniform(0.0, 1.0), n_samples=2_000_000)
+    assert len(r.values) == 1 and abs(r.values[0] - 2 / 3) < 0.01
+    for size in (100, 500, 1000):                                       # :348-363
+        x = np.linspace(-5, 5, size)
+        t = D().from_pdf_table(x, np.exp(-0.5 * x * x) / np.sqrt(2 * np.pi))
+        r = mc.integrate_importance_sampling([lambda x: x**2], t, D().normal(0.0, 2.0), n_samples=2_000_000)
+        assert abs(r.values[0] - 1.0) < 0.05
+    # WGSL-string integrand inside importance sampling (:133-148)
+    r = mc.integrate_importance_sampling(["fn f(x: f32) -> f32 { return x * x; }"], D().normal(0.0, 1.0),
+                                         D().normal(0.0, 2.0), n_samples=2_000_000)
+    assert abs(r.values[0] - 1.0) < 0.05
+
+
+# ---- tests/test_mcmc.py ---------------------------------------------------------------------------
+def test_mcmc_cases(mc):                                               # :91-299
+    fns = [lambda x: x, lambda x: x**2]
+    r = mc.integrate_mcmc(fns, D().normal(0.0, 1.0), D().normal(0.0, 1.5), n_steps=10_000, n_chains=1024, n_burnin=1000)
+    assert abs(r.values[0]) < 0.1 and abs(r.values[1] - 1.0) < 0.1
+    assert r.n_samples == 1024 * 10_000 and 0.7 < r.meta["accept_rate"] < 0.8
+    r = mc.integrate_mcmc(fns, D().normal(0.0, 1.0), D().normal(0.0, 1.0), n_steps=2000, n_chains=256, n_burnin=0)
+    assert r.meta["accept_rate"] == 1.0                                 # p == q: every proposal accepted (:94)
+    r = mc.integrate_mcmc(fns, D().exponential(1.0), D().exponential(0.5), n_steps=5000, n_chains=512)
+    assert abs(r.values[0] - 1.0) < 0.1 and abs(r.values[1] - 2.0) < 0.3
+    r = mc.integrate_mcmc(fns, D().uniform(0.0, 1.0), D().uniform(0.0, 1.0), n_steps=2000, n_chains=256)
+    assert abs(r.values[0] - 0.5) < 0.05
+    r = mc.integrate_mcmc([lambda x: x], D().normal(0.0, 1.0), D().normal(0.0, 2.0), n_steps=3000, n_chains=1)
+    assert r.meta["n_eff"] == 256 * 3000 and abs(r.values[0]) < 0.1     # one chain still runs 256 (:283-299)
+
+
+def test_mcmc_custom_targets_and_reproducibility(mc):                  # :319-392
+    bim = D().from_pdf(lambda x: 0.5 * (math.exp(-0.5 * (x - 2) ** 2) + math.exp(-0.5 * (x + 2) ** 2)), support=(-10, 10))
+    a = mc.integrate_mcmc([lambda x: x, lambda x: x**2], bim, D().normal(0.0, 2.0), n_steps=5000, n_chains=1024, seed=9)
+    b = mc.integrate_mcmc([lambda x: x, lambda x: x**2], bim, D().normal(0.0, 2.0), n_steps=5000, n_chains=1024, seed=9)
+    assert np.array_equal(a.values, b.values)                            # same seed -> identical (:319-344)
+    assert abs(a.values[0]) < 0.3 and abs(a.values[1] - 5.0) < 0.3
+    c = mc.integrate_mcmc([lambda x: x, lambda x: x**2], bim, D().normal(0.0, 2.0), n_steps=5000, n_chains=1024, seed=10)
+    assert not np.array_equal(a.values, c.values)
+    r = mc.integrate_mcmc([lambda x: x], D().beta(2.0, 5.0), D().uniform(0.0, 1.0), n_steps=5000, n_chains=512)
+    assert abs(r.values[0] - 2 / 7) < 0.02
+
+
+def test_closure_values_are_recaptured_between_calls(mc):
+    """The lowering is cached per code object; captured constants must not be."""
+    def make(a):
+        return lambda x: a * x * x
+
+    r2 = mc.integrate([make(2.0)], D().normal(0.0, 1.0), n_samples=1_000_000, seed=1)
+    r5 = mc.integrate([make(5.0)], D().normal(0.0, 1.0), n_samples=1_000_000, seed=1)
+    assert r5.values[0] == pytest.approx(2.5 * r2.values[0], rel=1e-6)
+
+
+def test_math_modes_agree(mc):
+    from wgpu_montecarlo import MonteCarloIntegrator
+
+    fns = [lambda x: math.exp(-x * x / 2) / math.sqrt(2 * math.pi), lambda x: math.sin(x) / (1.0 + x * x)]
+    vals = {m: MonteCarloIntegrator(math=m).integrate(fns, D().normal(0.0, 2.0), n_samples=2_000_000, seed=3).values
+            for m in ("precise", "default", "fast")}
+    assert np.allclose(vals["default"], vals["precise"], atol=2e-6)
+    assert np.allclose(vals["fast"], vals["precise"], atol=2e-5)

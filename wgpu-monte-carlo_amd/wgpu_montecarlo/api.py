@@ -64,14 +64,30 @@ def _check_count(value, name: str, bits: int = 64) -> int:
     return int(value)
 
 
+_EMIT_CACHE = {}      # (code object | wgsl text, slot, math, captured constants) -> HIP text
+
+
+def _emit_cached(key, build):
+    text = _EMIT_CACHE.get(key)
+    if text is None:
+        text = build()
+        if len(_EMIT_CACHE) > 4096:
+            _EMIT_CACHE.clear()
+        _EMIT_CACHE[key] = text
+    return text
+
+
 def functions_to_hip(functions: Sequence[FunctionLike], math="default") -> str:
     """Emit `user_func_0 .. user_func_{K-1}` (HIP C++) for callables and raw WGSL strings."""
     parts = [emit_hip.prelude()]
     for i, fn in enumerate(functions):
         if callable(fn):
-            parts.append(emit_hip.emit_function(frontend.lower(fn), f"user_func_{i}", math))
+            ir_fn = frontend.lower(fn)
+            name = f"user_func_{i}"
+            key = (getattr(fn, "__code__", None), name, math, tuple(ir_fn.consts.items()))
+            parts.append(_emit_cached(key, lambda: emit_hip.emit_function(ir_fn, name, math)))
         elif isinstance(fn, str):
-            parts.append(wgsl_to_hip.translate(fn, i, f"user_func_{i}"))
+            parts.append(_emit_cached((fn, i, "wgsl"), lambda: wgsl_to_hip.translate(fn, i, f"user_func_{i}")))
         else:
             raise TypeError(f"Function must be callable or WGSL string, got {type(fn)}")
     return "\n\n".join(parts)

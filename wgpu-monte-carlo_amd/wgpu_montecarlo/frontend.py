@@ -184,6 +184,9 @@ def _pin_source(func: Callable) -> None:
     linecache.cache[path] = (sum(len(l) for l in lines), None, lines, path)
 
 
+_FILE_TREES: Dict[str, tuple] = {}       # path -> (mtime, tree)
+
+
 def _file_tree(func: Callable) -> Optional[ast.AST]:
     try:
         path = inspect.getsourcefile(func)
@@ -192,8 +195,18 @@ def _file_tree(func: Callable) -> Optional[ast.AST]:
     if not path:
         return None
     try:
+        import os
+
+        mtime = os.stat(path).st_mtime_ns
+        hit = _FILE_TREES.get(path)
+        if hit is not None and hit[0] == mtime:
+            return hit[1]
         with open(path, "r") as fh:
-            return ast.parse(fh.read())
+            tree = ast.parse(fh.read())
+        if len(_FILE_TREES) > 64:
+            _FILE_TREES.clear()
+        _FILE_TREES[path] = (mtime, tree)
+        return tree
     except (OSError, SyntaxError, ValueError):
         return None
 
@@ -499,10 +512,51 @@ def _names_in(nodes) -> Tuple[Set[str], Set[str]]:
     return used, assigned
 
 
+class _Lowered:
+    """Everything about a function that is fixed by its code object; captured constants are not."""
+
+    __slots__ = ("name", "params", "body", "used", "assigned", "imports", "module_aliases")
+
+    def __init__(self, name, params, body, used, assigned, imports, module_aliases):
+        self.name, self.params, self.body = name, params, body
+        self.used, self.assigned = used, assigned
+        self.imports, self.module_aliases = imports, module_aliases
+
+
+_LOWER_CACHE: Dict[object, object] = {}       # code object -> _Lowered | TranspilerError
+_LOWER_CACHE_LIMIT = 4096
+
+
 def lower(func: Callable) -> Function:
-    """Lower a Python function or lambda to the IR (raises TranspilerError outside the subset)."""
+    """Lower a Python function or lambda to the IR (raises TranspilerError outside the subset).
+
+    The structural part (source recovery, parsing, import analysis, IR) is memoised per code object -- the
+    reference repeats it on every call (transpiler.py:160-182, 369-403); free variables are re-captured
+    from the closure / globals each time, so changed values are picked up."""
     if not callable(func) or not hasattr(func, "__code__"):
         raise TranspilerError(f"Could not get source code: {type(func).__name__} is not a Python function")
+    code = func.__code__
+    rec = _LOWER_CACHE.get(code)
+    if rec is None:
+        try:
+            rec = _lower_structure(func)
+        except TranspilerError as exc:
+            if not str(exc).startswith(("Undefined variable", "Unsupported external variable")):
+                if len(_LOWER_CACHE) < _LOWER_CACHE_LIMIT:
+                    _LOWER_CACHE[code] = exc          # structural rejection: permanent for this code object
+            raise
+        if len(_LOWER_CACHE) >= _LOWER_CACHE_LIMIT:
+            _LOWER_CACHE.clear()
+        _LOWER_CACHE[code] = rec
+    elif isinstance(rec, TranspilerError):
+        raise TranspilerError(str(rec))
+    low = _Lowering()
+    low.imports, low.module_aliases = rec.imports, rec.module_aliases
+    consts = low.capture(func, set(rec.params), rec.used, rec.assigned)
+    return Function(rec.name, list(rec.params), consts, rec.body)
+
+
+def _lower_structure(func: Callable) -> _Lowered:
     is_lambda = func.__name__ == "<lambda>"
     if is_lambda:
         _pin_source(func)
@@ -545,16 +599,17 @@ def lower(func: Callable) -> Function:
         node = lambdas[0] if len(lambdas) == 1 else _pick_lambda(lambdas, func, margin)
         params = [a.arg for a in node.args.args]
         used, _ = _names_in([node.body])
-        consts = low.capture(func, set(params), used, set())
+        low.capture(func, set(params), used, set())          # the reference checks free variables first
         body_is_bool = isinstance(node.body, (ast.Compare, ast.BoolOp))
         body = [Return(low.expr(node.body), boolean=body_is_bool)]
-        return Function(f"user_func_{uuid.uuid4().hex[:8]}", params, consts, body)
+        return _Lowered(f"user_func_{uuid.uuid4().hex[:8]}", params, body, used, set(), low.imports,
+                        low.module_aliases)
 
     definition = next((n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)), None)
     if definition is None:
         raise TranspilerError("No function definition found")
     params = [a.arg for a in definition.args.args]
     used, assigned = _names_in(definition.body)
-    consts = low.capture(func, set(params), used, assigned)
+    low.capture(func, set(params), used, assigned)           # the reference checks free variables first
     body = [low.stmt(s) for s in definition.body]
-    return Function(definition.name, params, consts, body)
+    return _Lowered(definition.name, params, body, used, assigned, low.imports, low.module_aliases)
