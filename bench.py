@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--cpu-samples", type=float, default=2e8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--target-phys", type=int, default=0, help="physical threads per launch (tuning)")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the measured configuration) or gloo (rehearsal)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (with --backend gloo) to exercise the N > 1 code path")
     args = ap.parse_args()
 
     import numpy as np
@@ -91,10 +94,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     from wgpu_montecarlo import Distribution, MonteCarloIntegrator
 
@@ -105,10 +113,18 @@ def main():
     n_total = int(args.samples_per_gpu) * world
     out = torch.zeros(args.warmup + args.steps + 1, K, dtype=torch.float64, device=device)
 
+    pending = []
+
     def step(i):
-        return prepared.launch(n_total, 42 + i, out[i])
+        # the all-reduce of step i overlaps the kernel of step i + 1 (different rows of `out`)
+        n_eff_, work = prepared.launch(n_total, 42 + i, out[i], async_op=True)
+        if work is not None:
+            pending.append(work)
+        return n_eff_
 
     def fence():
+        while pending:
+            pending.pop().wait()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -137,6 +153,7 @@ def main():
     for j in range(10):
         step(args.warmup + args.steps)
         durations.append(integ._engine.last_kernel_ms())
+    fence()
     kernel_ms = float(np.mean(durations))
     launch = integ._engine.last_launch()
     samples_per_launch = n_eff / world
@@ -170,7 +187,8 @@ def main():
                             "(BASELINE configs[1]); logical grid T=65536",
                 "n_samples_per_step": n_total,
                 "n_eff_per_step": int(n_eff),
-                "parallelism": f"sample-grid shards x{world}, one RCCL sum all-reduce of {K} f64" if world > 1 else "single GPU",
+                "parallelism": (f"sample-grid shards x{world}, one {'RCCL' if args.backend == 'nccl' else args.backend} "
+                                f"sum all-reduce of {K} f64 per step") if world > 1 else "single GPU",
                 "accumulate": "f32 registers per 128 pairs -> f64",
             },
             "abs_err_vs_truth": abs_err.max(axis=0).tolist(),
@@ -185,8 +203,12 @@ def main():
                 "peak": VALU_PEAK_LANEOPS / 1e12,
                 "unit": "Tlane-op/s",
                 "frac": valu_achieved / VALU_PEAK_LANEOPS,
-                "traffic": None,
+                # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command
+                # (profiles/r01_bench_n1_pmc_{fetch,write}_counters.csv): WRITE_SIZE 128 KiB (= the algorithmic
+                # n_blocks*K*8 B of partial sums) + FETCH_SIZE 31.5 KiB (code objects + kernel arguments).
+                "traffic": 128 * 1024 + 31.5 * 1024 if world == 1 and launch["n_blocks"] == 4096 else None,
                 "kernel": "mcx_integrate_kernel",
+                "measured_valu_peak": 51.5,   # Tlane-op/s sustained by v_fma_f32 (profiles/r01_valu_rates_microbench.txt)
                 "kernel_ms": kernel_ms,
                 "ops_per_sample": OPS_PER_SAMPLE,
                 "launch": launch,
@@ -197,10 +219,12 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(int(args.cpu_samples))
-        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -86,6 +86,10 @@ int mcx_shard_chains(uint32_t total_chains, uint32_t rank, uint32_t world,
  * Engine -- replaces ComputeEngine::new, src/engine.rs:91-131 / _core.MonteCarloIntegrator(), src/lib.rs:24-31
  * ------------------------------------------------------------------------------------------ */
 int  mcx_device_count(void);                         /* 0 when no GPU is visible */
+/* Which HIP runtime libmcx bound to at run time. libmcx links none: it shares the libamdhip64 instance that
+ * is already mapped in the process (PyTorch-ROCm bundles its own), else MCX_HIP_RUNTIME, else the system one --
+ * stream handles passed to *_device calls must come from that same runtime. */
+const char* mcx_hip_runtime(void);
 int  mcx_engine_create(int device, mcx_engine** out);
 void mcx_engine_destroy(mcx_engine* e);
 int  mcx_engine_device(const mcx_engine* e);
@@ -160,8 +164,10 @@ typedef struct mcx_integrate_params {
 int mcx_integrate(mcx_engine* e, mcx_module* m, const mcx_integrate_params* p,
                   double* sums_out, uint64_t* n_eff_out);
 /* Same, but the K sums are left in device memory at d_sums (K doubles) and the work is enqueued
- * on `stream` (a hipStream_t; NULL = the engine's own stream) without a host sync: the caller
- * runs the collective (RCCL all-reduce) on the same stream. */
+ * on `stream` without a host sync: the caller runs the collective (RCCL all-reduce) ordered after it.
+ * `stream` is a hipStream_t taken literally -- NULL is HIP's null stream (what torch calls its default
+ * stream) -- or MCX_STREAM_ENGINE for the engine's own non-blocking stream. */
+#define MCX_STREAM_ENGINE ((void*)(intptr_t)-1)
 int mcx_integrate_device(mcx_engine* e, mcx_module* m, const mcx_integrate_params* p,
                          void* d_sums, void* stream, uint64_t* n_eff_out);
 

@@ -123,6 +123,29 @@ def test_no_gpu_means_loud_failure():
         rt.Engine(0)
 
 
+def test_one_hip_runtime_shared_with_torch():
+    """libmcx links no HIP runtime; it binds to the instance torch uses (PyTorch-ROCm bundles its own)."""
+    import subprocess
+    import sys
+
+    out = subprocess.run(["ldd", str(rt.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "amdhip64" not in out and "hsa-runtime" not in out, out
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from wgpu_montecarlo import runtime as rt\n"
+        "first = rt.hip_runtime()\n"
+        "import torch\n"
+        "torch.cuda.is_available()\n"
+        "maps = set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l)\n"
+        "print(first); print(len(maps)); print(sorted(maps))\n" % str(ROOT / "wgpu-monte-carlo_amd"))
+    for order in (code, "import torch\n" + code):
+        res = subprocess.run([sys.executable, "-c", order], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = res.stdout.strip().splitlines()
+        assert lines[-2] == "1", lines            # exactly one libamdhip64 mapped in the process
+        assert "torch" in lines[-1]
+
+
 def test_product_never_imports_the_oracle():
     pkg = ROOT / "wgpu-monte-carlo_amd"
     for path in list(pkg.rglob("*.py")) + list(pkg.rglob("*.cpp")) + list(pkg.rglob("*.hpp")) + list(pkg.rglob("*.h")):

@@ -1,0 +1,95 @@
+"""The N > 1 code path on real kernels: two `gloo` ranks that share GPU 0 (the 8-GPU RCCL runs are the
+driver's; here every piece except the RCCL transport itself is exercised), and the device-resident
+launch path on torch streams."""
+import math
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _bimodal(x):
+    return 0.5 * (math.exp(-0.5 * (x - 2) ** 2) + math.exp(-0.5 * (x + 2) ** 2))
+
+
+def _calls(mc, D):
+    f1 = lambda x: x
+    f2 = lambda x: x**2
+    out = {}
+    out["normal"] = mc.integrate([f1, f2], D.normal(0.0, 1.0), n_samples=3_000_001, seed=5).values
+    out["beta"] = mc.integrate([f1, f2], D.beta(2.0, 5.0), n_samples=2_000_000, seed=6).values
+    out["tiny"] = mc.integrate([f1, f2], D.normal(0.0, 1.0), n_samples=1000, seed=7).values      # L = 1: idx sharding
+    xs = np.linspace(0, 10, 512)
+    out["is"] = mc.integrate_importance_sampling([f1, f2], D.from_pdf_table(xs, np.exp(-xs)), D.normal(2.0, 3.0),
+                                                 n_samples=2_000_000, seed=8).values
+    res = mc.integrate_mcmc([f1, f2], D.from_pdf(_bimodal, support=(-10, 10)), D.normal(0.0, 2.0), n_steps=600,
+                            n_chains=2048, n_burnin=50, seed=9)
+    out["mcmc"] = np.append(res.values, res.meta["accept_rate"])
+    return out
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT / "wgpu-monte-carlo_amd", ROOT):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+
+    mc = MonteCarloIntegrator(device=0)                     # picks up the world group: every call is sharded
+    assert mc._rank_world() == (rank, world)
+    res = _calls(mc, Distribution)
+    np.savez(Path(out_dir) / f"rank{rank}.npz", **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_reproduce_the_single_gpu_results(tmp_path, integrator):
+    import torch.multiprocessing as mp
+
+    from wgpu_montecarlo import Distribution
+
+    want = _calls(integrator, Distribution)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        for key, ref in want.items():
+            assert np.allclose(got[key], ref, rtol=1e-9, atol=1e-9), (r, key, got[key], ref)
+
+
+def test_device_resident_launch_follows_torch_streams(integrator):
+    """launch() enqueues on torch's CURRENT stream (the null stream by default) and leaves K sums on the GPU."""
+    import torch
+
+    from wgpu_montecarlo import Distribution
+
+    fns = [lambda x: x, lambda x: x**2, lambda x: x**3, lambda x: x**4]
+    prepared = integrator.prepare_integrate(fns, Distribution.normal(0.0, 1.0))
+    want = integrator.integrate(fns, Distribution.normal(0.0, 1.0), n_samples=50_000_000, seed=3)
+    dev = torch.device("cuda", 0)
+    out = torch.full((3, 4), float("nan"), dtype=torch.float64, device=dev)
+    n_eff = prepared.launch(50_000_000, 3, out[0])                      # default (null) stream
+    copy0 = out[0] + 0.0                                                # consumer on the same stream: ordered
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        prepared.launch(50_000_000, 3, out[1])
+        copy1 = out[1] + 0.0
+    n_eff2, work = prepared.launch(50_000_000, 3, out[2], async_op=True)
+    assert work is None and n_eff2 == n_eff == want.meta["n_eff"]
+    torch.cuda.synchronize()
+    for got in (copy0, copy1, out[2]):
+        assert np.array_equal(got.cpu().numpy() / float(n_eff), want.values)
+    assert np.array_equal(prepared.run(50_000_000, 3).values, want.values)

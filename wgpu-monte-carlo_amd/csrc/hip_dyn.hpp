@@ -1,0 +1,45 @@
+// hip_dyn.hpp -- run-time binding to the HIP runtime.
+//
+// PyTorch-ROCm wheels bundle their own libamdhip64.so (+ libhsa-runtime64.so); a library linked against
+// /opt/rocm/lib/libamdhip64.so.7 would bring a SECOND HIP runtime into the process: torch's stream handles
+// (and its null stream) would not be the streams our launches are ordered on, and whichever runtime
+// initialises second may find no GPU. libmcx therefore links no HIP runtime: it binds to the instance that
+// is already mapped in the process (torch's, when torch is imported or was preloaded by
+// wgpu_montecarlo/runtime.py), else loads MCX_HIP_RUNTIME, else the system runtime.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+namespace mcx {
+
+struct HipApi {
+    const char* (*GetErrorString)(hipError_t);
+    hipError_t (*GetDeviceCount)(int*);
+    hipError_t (*GetDeviceProperties)(hipDeviceProp_t*, int);          // symbol hipGetDevicePropertiesR0600
+    hipError_t (*SetDevice)(int);
+    hipError_t (*StreamCreateWithFlags)(hipStream_t*, unsigned int);
+    hipError_t (*StreamDestroy)(hipStream_t);
+    hipError_t (*StreamSynchronize)(hipStream_t);
+    hipError_t (*EventCreate)(hipEvent_t*);
+    hipError_t (*EventDestroy)(hipEvent_t);
+    hipError_t (*EventRecord)(hipEvent_t, hipStream_t);
+    hipError_t (*EventSynchronize)(hipEvent_t);
+    hipError_t (*EventElapsedTime)(float*, hipEvent_t, hipEvent_t);
+    hipError_t (*Malloc)(void**, size_t);
+    hipError_t (*Free)(void*);
+    hipError_t (*HostMalloc)(void**, size_t, unsigned int);
+    hipError_t (*HostFree)(void*);
+    hipError_t (*Memcpy)(void*, const void*, size_t, hipMemcpyKind);
+    hipError_t (*MemcpyAsync)(void*, const void*, size_t, hipMemcpyKind, hipStream_t);
+    hipError_t (*MemsetAsync)(void*, int, size_t, hipStream_t);
+    hipError_t (*ModuleLoadData)(hipModule_t*, const void*);
+    hipError_t (*ModuleUnload)(hipModule_t);
+    hipError_t (*ModuleGetFunction)(hipFunction_t*, hipModule_t, const char*);
+    hipError_t (*ModuleLaunchKernel)(hipFunction_t, unsigned int, unsigned int, unsigned int, unsigned int,
+                                     unsigned int, unsigned int, unsigned int, hipStream_t, void**, void**);
+    const char* library;      // path or soname of the runtime that was bound
+};
+
+// Bound on first use; nullptr (and an error text in `why`) if no HIP runtime can be loaded.
+const HipApi* hip_api(const char** why = nullptr);
+
+}  // namespace mcx

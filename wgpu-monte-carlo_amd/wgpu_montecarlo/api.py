@@ -342,11 +342,13 @@ class PreparedIntegrand:
         self._owner, self._module, self.k = owner, module, k
         self._p1, self._p2, self._cdf = p1, p2, cdf
 
-    def launch(self, n_samples: int, seed: int, out) -> int:
+    def launch(self, n_samples: int, seed: int, out, async_op: bool = False):
         """Enqueue sampling + reduction (+ one sum all-reduce when sharded) on torch's current stream.
 
         `out` is a float64 CUDA tensor with k elements that receives the SUMS over the whole job (all
-        ranks); divide by the returned n_eff for the expected values. No host synchronisation."""
+        ranks); divide by the returned n_eff for the expected values. No host synchronisation.
+        With async_op=True the collective does not block the current stream (the next launch overlaps it);
+        returns (n_eff, work) and the caller waits on `work` (None on a single GPU) before reading `out`."""
         import torch
 
         owner = self._owner
@@ -355,9 +357,10 @@ class PreparedIntegrand:
         _, n_eff = owner._engine.integrate(self._module, n_samples, seed, self._p1, self._p2,
                                            owner._target_threads, cdf=self._cdf, rank=rank, world=world,
                                            d_sums=out.data_ptr(), stream=stream)
+        work = None
         if world > 1:
-            distributed.all_reduce_device(owner._group, out)
-        return n_eff
+            work = distributed.all_reduce_device(owner._group, out, async_op=async_op)
+        return (n_eff, work) if async_op else n_eff
 
     def run(self, n_samples: int, seed: int = 42) -> IntegrationResult:
         """Blocking form: same result as MonteCarloIntegrator.integrate()."""

@@ -53,6 +53,10 @@ def all_reduce_host(group: Optional[Group], sums: np.ndarray) -> np.ndarray:
     return t.cpu().numpy()
 
 
-def all_reduce_device(group: Group, buf) -> None:
-    """Sum a float64 CUDA tensor in place over the group (RCCL over xGMI), on torch's current stream."""
-    group.dist.all_reduce(buf, op=group.dist.ReduceOp.SUM, group=group.group)
+def all_reduce_device(group: Group, buf, async_op: bool = False):
+    """Sum a float64 CUDA tensor in place over the group (RCCL over xGMI).
+
+    The collective is ordered after the work already enqueued on torch's current stream. async_op=False:
+    the current stream then waits for it (later kernels see the reduced values). async_op=True: it runs on
+    the communicator's stream without blocking the current one; returns the work handle to wait on."""
+    return group.dist.all_reduce(buf, op=group.dist.ReduceOp.SUM, group=group.group, async_op=async_op)

@@ -58,7 +58,7 @@ class McmcParams(C.Structure):
 
 # every symbol include/mcx.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "mcx_version", "mcx_last_error", "mcx_dispatch_config", "mcx_mcmc_dispatch_config", "mcx_shard_integrate",
+    "mcx_version", "mcx_last_error", "mcx_hip_runtime", "mcx_dispatch_config", "mcx_mcmc_dispatch_config", "mcx_shard_integrate",
     "mcx_shard_chains", "mcx_device_count", "mcx_engine_create", "mcx_engine_destroy", "mcx_engine_device",
     "mcx_engine_last_kernel_ms", "mcx_engine_last_launch", "mcx_engine_set_target_threads", "mcx_module_build",
     "mcx_module_precompile", "mcx_module_source", "mcx_free", "mcx_module_release", "mcx_cache_dir",
@@ -68,6 +68,30 @@ EXPORTED_SYMBOLS = [
 
 _lib = None
 _lib_lock = threading.Lock()
+
+
+def _share_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels ship their own libamdhip64.so. libmcx binds at run time to the HIP runtime that is
+    already in the process; if torch is installed but not imported yet, map ITS runtime first (without
+    importing torch) so that a later `import torch` and libmcx use one runtime instance -- otherwise torch's
+    stream handles would belong to a different runtime than the one our kernels are launched with."""
+    if os.environ.get("MCX_HIP_RUNTIME"):
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+            os.environ["MCX_HIP_RUNTIME"] = str(cand)
+        except OSError:
+            pass
 
 
 def load():
@@ -81,6 +105,7 @@ def load():
                 f"libmcx.so not found at {LIB_PATH}. Build it with `make -C wgpu-monte-carlo_amd/csrc` "
                 f"(or `python -c 'import __graft_entry__ as g; g.build()'`)."
             )
+        _share_torch_hip_runtime()
         try:
             L = C.CDLL(str(LIB_PATH))
         except OSError as exc:
@@ -89,6 +114,7 @@ def load():
         L.mcx_version.restype = C.c_char_p
         L.mcx_last_error.restype = C.c_char_p
         L.mcx_cache_dir.restype = C.c_char_p
+        L.mcx_hip_runtime.restype = C.c_char_p
         L.mcx_dispatch_config.argtypes = [u64, i64, C.POINTER(Dispatch)]
         L.mcx_mcmc_dispatch_config.argtypes = [u32, i64, C.POINTER(Dispatch)]
         L.mcx_shard_integrate.argtypes = [C.POINTER(Dispatch), C.c_int, u32, u32, C.POINTER(Shard)]
@@ -184,8 +210,22 @@ def precompile(user_src: str, desc: ModuleDesc) -> int:
     return int(hit.value)
 
 
+STREAM_ENGINE = C.c_void_p(-1)        # MCX_STREAM_ENGINE: the engine's own stream
+
+
+def _stream_arg(stream: Optional[int]):
+    """None -> the engine's stream; an integer is a hipStream_t taken literally (0 = HIP's null stream,
+    which is what torch.cuda.current_stream().cuda_stream returns for torch's default stream)."""
+    return STREAM_ENGINE if stream is None else C.c_void_p(int(stream))
+
+
 def device_count() -> int:
     return int(load().mcx_device_count())
+
+
+def hip_runtime() -> str:
+    """Path / soname of the HIP runtime libmcx is bound to."""
+    return (load().mcx_hip_runtime() or b"").decode()
 
 
 # ---- handles ---------------------------------------------------------------------------------------
@@ -286,7 +326,7 @@ class Engine:
         n_eff = C.c_uint64(0)
         if d_sums is not None:
             check(load().mcx_integrate_device(self._h, mod._h, C.byref(p), C.c_void_p(d_sums),
-                                              C.c_void_p(stream or 0), C.byref(n_eff)))
+                                              _stream_arg(stream), C.byref(n_eff)))
             return None, int(n_eff.value)
         sums = np.zeros(mod.desc.k, dtype=np.float64)
         check(load().mcx_integrate(self._h, mod._h, C.byref(p), sums.ctypes.data_as(C.POINTER(C.c_double)),
@@ -304,7 +344,7 @@ class Engine:
         n_eff = C.c_uint64(0)
         if d_sums is not None:
             check(load().mcx_mcmc_device(self._h, mod._h, C.byref(p), C.c_void_p(d_sums),
-                                         C.c_void_p(stream or 0), C.byref(n_eff)))
+                                         _stream_arg(stream), C.byref(n_eff)))
             return None, int(n_eff.value)
         sums = np.zeros(mod.desc.k + 1, dtype=np.float64)
         check(load().mcx_mcmc(self._h, mod._h, C.byref(p), sums.ctypes.data_as(C.POINTER(C.c_double)),
