@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--cpu-samples", type=float, default=2e8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--target-phys", type=int, default=0, help="physical threads per launch (tuning)")
+    ap.add_argument("--rng", default="pcg_ref", help="pcg_ref (the reference's stream; the headline) or philox")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the measured configuration) or gloo (rehearsal)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (with --backend gloo) to exercise the N > 1 code path")
@@ -106,7 +107,7 @@ def main():
 
     from wgpu_montecarlo import Distribution, MonteCarloIntegrator
 
-    integ = MonteCarloIntegrator(device=local_rank)
+    integ = MonteCarloIntegrator(device=local_rank, rng=args.rng)
     if args.target_phys:
         integ._engine.set_target_threads(args.target_phys)
     prepared = integ.prepare_integrate(moment_functions(), Distribution.normal(0.0, 1.0))
@@ -190,6 +191,7 @@ def main():
                 "parallelism": (f"sample-grid shards x{world}, one {'RCCL' if args.backend == 'nccl' else args.backend} "
                                 f"sum all-reduce of {K} f64 per step") if world > 1 else "single GPU",
                 "accumulate": "f32 registers per 128 pairs -> f64",
+                "rng": args.rng,
             },
             "abs_err_vs_truth": abs_err.max(axis=0).tolist(),
             "three_sigma": three_sigma.tolist(),

@@ -77,6 +77,9 @@ typedef struct mcx_shard {
     uint32_t unit_begin, unit_end;
 } mcx_shard;
 int mcx_shard_integrate(const mcx_dispatch* d, int dist_type, uint32_t rank, uint32_t world, mcx_shard* out);
+/* Same with an explicit unit size: iterations per unit = 1 (uniform / exponential / custom), 2 (normal: a
+ * Box-Muller pair), 4 (Philox stream: one call). */
+int mcx_shard_units(const mcx_dispatch* d, uint32_t iterations_per_unit, uint32_t rank, uint32_t world, mcx_shard* out);
 
 /* One rank's contiguous share of the padded chain range [0, T), in multiples of 256 chains. */
 int mcx_shard_chains(uint32_t total_chains, uint32_t rank, uint32_t world,
@@ -121,7 +124,13 @@ typedef struct mcx_module_desc {
     int32_t precise_sampler;   /* 1: ocml log/sin/cos in the samplers; 0: v_log/v_sin/v_cos */
     int32_t block;             /* threads per workgroup: 0 = auto (256, or 1024 when tables are staged) */
     int32_t tables_lds;        /* 1 (default): tables staged in LDS; 0: read from HBM/L2 */
+    int32_t rng;               /* 0 (default): the reference's PCG counter hash (parity stream);
+                                * 1: Philox4x32-10, counter (idx, i/4, 0, 0), key (seed, 'MCX1') -- opt-in for runs that
+                                * draw more than ~2^32 uniforms (K1/K2 only) */
 } mcx_module_desc;
+
+#define MCX_RNG_PCG_REF 0
+#define MCX_RNG_PHILOX  1
 
 /* user_src: HIP C++ text defining `__device__ float user_func_i(float x)` for i < k (and
  * mcx_pdf_p / mcx_pdf_q when weight && !p_table / !q_table). */

@@ -41,7 +41,7 @@ class _K1Args(C.Structure):
                 ("dist_type", C.c_int32), ("param1", C.c_float), ("param2", C.c_float),
                 ("table_size", C.c_uint32), ("cdf_table", C.POINTER(C.c_float)),
                 ("x_table", C.POINTER(C.c_float)), ("guard", C.c_int32), ("weighted", C.c_int32),
-                ("p", _Pdf), ("q", _Pdf)]
+                ("p", _Pdf), ("q", _Pdf), ("rng", C.c_int32)]
 
 
 class _McmcArgs(C.Structure):
@@ -65,6 +65,7 @@ def lib():
         L.orc_pcg_hash.argtypes = [C.c_uint32]
         L.orc_combined.restype = C.c_uint32
         L.orc_combined.argtypes = [C.c_uint32] * 3
+        L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
         L.orc_random_uniform.restype = C.c_float
         L.orc_random_uniform.argtypes = [C.c_uint32] * 3
         L.orc_dispatch_config.argtypes = [C.c_uint64, C.c_int64, C.POINTER(C.c_uint32)]
@@ -161,7 +162,16 @@ def _pdf(spec, keep):
     return p
 
 
-def _k1_args(n_samples, seed, dist_type, param1, param2, cdf_table, x_table, target_threads, guard, p, q, keep):
+def philox4x32_10(counter, key):
+    """Philox4x32-10 block function (libmcx's opt-in stream; not part of the reference)."""
+    c = (C.c_uint32 * 4)(*[v & 0xFFFFFFFF for v in counter])
+    k = (C.c_uint32 * 2)(*[v & 0xFFFFFFFF for v in key])
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return tuple(int(v) for v in o)
+
+
+def _k1_args(n_samples, seed, dist_type, param1, param2, cdf_table, x_table, target_threads, guard, p, q, keep, rng=0):
     a = _K1Args()
     a.n_samples = int(n_samples)
     a.target_threads = int(target_threads or 0)
@@ -175,16 +185,17 @@ def _k1_args(n_samples, seed, dist_type, param1, param2, cdf_table, x_table, tar
     a.guard = int(guard)
     a.weighted = int(p is not None or q is not None)
     a.p, a.q = _pdf(p, keep), _pdf(q, keep)
+    a.rng = int(rng)
     return a
 
 
 def integrate(fns, dist_type, param1=0.0, param2=1.0, n_samples=1_000_000, seed=42, cdf_table=None,
-              x_table=None, target_threads=None, guard=0, p=None, q=None):
+              x_table=None, target_threads=None, guard=0, p=None, q=None, rng=0):
     """Restated K1/K2. fns: list of (FN_*, a). p, q: None or (PDF_*, params...) / (PDF_TABLE, x, pdf).
 
     Returns dict(ref=float32[K] the reference's f32 result, sums=float64[K], n_eff=int)."""
     keep = []
-    a = _k1_args(n_samples, seed, dist_type, param1, param2, cdf_table, x_table, target_threads, guard, p, q, keep)
+    a = _k1_args(n_samples, seed, dist_type, param1, param2, cdf_table, x_table, target_threads, guard, p, q, keep, rng)
     K = len(fns)
     ref = np.zeros(K, dtype=np.float32)
     sums = np.zeros(K, dtype=np.float64)
@@ -196,10 +207,10 @@ def integrate(fns, dist_type, param1=0.0, param2=1.0, n_samples=1_000_000, seed=
 
 
 def samples(dist_type, param1=0.0, param2=1.0, n_samples=1_000_000, seed=42, cdf_table=None, x_table=None,
-            target_threads=None, guard=0, idx0=0, nidx=None):
+            target_threads=None, guard=0, idx0=0, nidx=None, rng=0):
     """x(idx, i) as float32[nidx, L] for evaluating arbitrary functions in numpy."""
     keep = []
-    a = _k1_args(n_samples, seed, dist_type, param1, param2, cdf_table, x_table, target_threads, guard, None, None, keep)
+    a = _k1_args(n_samples, seed, dist_type, param1, param2, cdf_table, x_table, target_threads, guard, None, None, keep, rng)
     cfg = dispatch_config(n_samples, target_threads)
     if nidx is None:
         nidx = cfg["total_threads"] - idx0

@@ -60,6 +60,21 @@ float orc_random_uniform(uint32_t seed, uint32_t idx, uint32_t iter) {
     return (float)h / 4294967296.0f;
 }
 
+/* ---------------------------------------------------------------- Philox4x32-10 (NOT in the reference)
+ * libmcx's opt-in stream (csrc/device/mcx_device.hpp): Salmon, Moraes, Dror, Shaw, "Parallel random numbers:
+ * as easy as 1, 2, 3", SC'11; pinned by the Random123 known-answer vectors in tests/test_oracle_pins.py. */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
 /* ---------------------------------------------------------------- dispatch (engine.rs:157-181, 821-832, 860) */
 void orc_dispatch_config(uint64_t n_samples, int64_t target_threads, uint32_t out[4]) {
     uint32_t target = target_threads > 0 ? (uint32_t)target_threads : 65536u;
@@ -229,9 +244,36 @@ typedef struct {
     int32_t  guard;           /* 0 strict reference, 1 libmcx default guards */
     int32_t  weighted;        /* 1: f*p/q */
     orc_pdf  p, q;
+    int32_t  rng;             /* 0: the reference's PCG counter hash; 1: libmcx's opt-in Philox stream */
 } orc_k1_args;
 
+/* Philox stream of libmcx: call j = i/4 with counter (idx, j, 0, 0), key (seed, 'MCX1'); output slot i%4.
+ * Normal: outputs (0,1) and (2,3) are Box-Muller pairs -> iterations (4j, 4j+1) and (4j+2, 4j+3). */
+static float k1_sample_philox(const orc_k1_args* a, uint32_t idx, uint32_t i) {
+    uint32_t ctr[4] = {idx, i / 4u, 0u, 0u}, key[2] = {a->seed, 0x4d435831u}, o[4];
+    orc_philox4x32_10(ctr, key, o);
+    uint32_t slot = i % 4u;
+    if (a->dist_type == ORC_DIST_NORMAL) {
+        uint32_t h1 = o[slot & 2u], h2 = o[(slot & 2u) + 1u];
+        float u1 = u_from_hash(h1);
+        if (a->guard && h1 == 0u) u1 = 0x1.0p-33f;
+        float u2 = u_from_hash(h2);
+        float r = sqrtf(-2.0f * logf(u1));
+        float theta = 6.283185307179586f * u2;
+        float z = (slot & 1u) ? r * sinf(theta) : r * cosf(theta);
+        return a->param1 + a->param2 * z;
+    }
+    float rng = u_from_hash(o[slot]);
+    if (a->dist_type == ORC_DIST_UNIFORM) {
+        if (a->guard && rng >= 1.0f) rng = 0x1.fffffep-1f;
+        return orc_sample_uniform(rng, a->param1, a->param2);
+    }
+    if (a->dist_type == ORC_DIST_EXPONENTIAL) return orc_sample_exponential(rng, a->param1);
+    return orc_sample_from_cdf_table(rng, a->table_size, a->cdf_table, a->x_table);
+}
+
 static float k1_sample(const orc_k1_args* a, orc_bm_state* bm, uint32_t idx, uint32_t i) {
+    if (a->rng == 1) return k1_sample_philox(a, idx, i);
     if (a->dist_type == ORC_DIST_NORMAL)
         return orc_sample_normal(bm, a->seed, idx, i, a->param1, a->param2, a->guard);
     uint32_t h = orc_pcg_hash(orc_combined(a->seed, idx, i));

@@ -304,3 +304,43 @@ def test_wgsl_string_functions(integrator):
                            seed=42, guard=1)
     ok, msg = close(res.values, ref["sums"] / ref["n_eff"])
     assert ok, msg
+
+
+@pytest.mark.parametrize("n_samples", [1_000_000, 1_000, 3_211_264, 200_000])
+def test_philox_stream_matches_its_oracle(n_samples):
+    """rng="philox" (opt-in, not in the reference): same samples as the oracle's restatement for L % 4 = 0, 1, 3, 0
+    and every distribution family; the Philox block function itself is pinned by the Random123 KATs."""
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+
+    mc = MonteCarloIntegrator(rng="philox")
+    res = mc.integrate(MOMENTS, Distribution.normal(0.5, 1.5), n_samples=n_samples, seed=77)
+    ref = oracle.integrate(ORC_MOMENTS, oracle.NORMAL, 0.5, 1.5, n_samples=n_samples, seed=77, guard=1, rng=1)
+    assert res.meta["n_eff"] == ref["n_eff"]
+    ok, msg = close(res.values, ref["sums"] / ref["n_eff"])
+    assert ok, msg
+    beta = Distribution.beta(2.0, 5.0)
+    for dist, code, p1, p2, kw in ((Distribution.uniform(-1.0, 3.0), oracle.UNIFORM, -1.0, 3.0, {}),
+                                   (Distribution.exponential(2.0), oracle.EXPONENTIAL, 2.0, 0.0, {}),
+                                   (beta, oracle.CUSTOM, 0.0, 0.0, dict(cdf_table=beta._cdf_table, x_table=beta._x_table))):
+        res = mc.integrate(MOMENTS[:2], dist, n_samples=n_samples, seed=5)
+        ref = oracle.integrate(ORC_MOMENTS[:2], code, p1, p2, n_samples=n_samples, seed=5, guard=1, rng=1, **kw)
+        ok, msg = close(res.values, ref["sums"] / ref["n_eff"])
+        assert ok, msg
+
+
+def test_philox_shards_and_full_size():
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+    from wgpu_montecarlo import runtime as rt
+    from wgpu_montecarlo.api import functions_to_hip
+
+    mc = MonteCarloIntegrator(rng="philox")
+    eng = mc._engine
+    mod = eng.module(functions_to_hip(MOMENTS), rt.make_desc(rt.KIND_INTEGRATE, 4, rt.DIST_NORMAL, rng=rt.RNG_PHILOX))
+    for n in (3_000_001, 70_000):
+        whole, n_eff = eng.integrate(mod, n, 5, 0.0, 1.0)
+        for world in (2, 3, 8):
+            parts = [eng.integrate(mod, n, 5, 0.0, 1.0, rank=r, world=world)[0] for r in range(world)]
+            assert np.allclose(np.sum(parts, axis=0), whole, rtol=1e-8, atol=1e-9 * n_eff)
+    res = mc.integrate(MOMENTS, Distribution.normal(0.0, 1.0), n_samples=10**9, seed=42)
+    sigma = np.sqrt(np.array([1.0, 2.0, 15.0, 96.0]) / res.meta["n_eff"])
+    assert np.all(np.abs(res.values - [0, 1, 0, 3]) < 3.5 * sigma), res.values

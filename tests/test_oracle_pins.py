@@ -156,3 +156,20 @@ def test_importance_sampling_algebra():
     r = oracle.integrate(MOM[:2], oracle.NORMAL, 0.5, 1.5, n_samples=5_000_000, seed=42,
                          p=(oracle.PDF_NORMAL, 0.0, 1.0, s2pi), q=(oracle.PDF_NORMAL, 0.5, 1.5, s2pi))
     assert abs(r["ref"][0]) < 0.05 and abs(r["ref"][1] - 1.0) < 0.05
+
+
+def test_philox4x32_10_random123_known_answers():
+    """libmcx's opt-in stream is not from the reference; it is pinned by the published Random123 vectors
+    (kat_vectors: philox4x32 10)."""
+    assert oracle.philox4x32_10((0, 0, 0, 0), (0, 0)) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
+    assert oracle.philox4x32_10((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2) == (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)
+    assert oracle.philox4x32_10((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0)) == (
+        0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)
+
+
+def test_philox_stream_statistics():
+    r = oracle.integrate(MOM, oracle.NORMAL, 0.0, 1.0, n_samples=10**7, seed=42, rng=1, guard=1)
+    sigma = np.sqrt(np.array([1, 2, 15, 96]) / r["n_eff"])
+    assert np.all(np.abs(r["sums"] / r["n_eff"] - [0, 1, 0, 3]) < 4 * sigma)
+    r = oracle.integrate(MOM[:2], oracle.UNIFORM, 0.0, 1.0, n_samples=10**7, seed=1, rng=1, guard=1)
+    assert abs(r["sums"][0] / r["n_eff"] - 0.5) < 4e-4 and abs(r["sums"][1] / r["n_eff"] - 1 / 3) < 4e-4

@@ -71,6 +71,31 @@ MCX_DEV float mcx_u01(u32 h) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// opt-in stream: Philox4x32-10 (Salmon et al., SC'11; Random123). Not in the reference -- its counter
+// hash has a 32-bit input space, so distinct (idx, iter) collide once a call draws more than ~2^32
+// uniforms. counter = (idx, unit, stream, 0), key = (seed, 0x4d435831): 128-bit
+// counter space, four u32 outputs per call = four samples (two Box-Muller pairs).
+// ---------------------------------------------------------------------------------------------
+#ifndef MCX_RNG
+#define MCX_RNG 0                  // 0: the reference's PCG counter hash (parity stream), 1: Philox4x32-10
+#endif
+#define MCX_PHILOX_KEY1 0x4d435831u
+
+struct McxU4 { u32 x, y, z, w; };
+
+MCX_DEV McxU4 mcx_philox4x32_10(McxU4 c, u32 k0, u32 k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const u32 hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const u32 hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = McxU4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------
 // samplers
 // ---------------------------------------------------------------------------------------------
 

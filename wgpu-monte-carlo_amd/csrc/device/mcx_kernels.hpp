@@ -215,7 +215,43 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         _Pragma("unroll") for (int k = 0; k < MCX_K; ++k) { accA[k] = 0.0f; MCX_ACC_B[k] = 0.0f; } \
     } while (0)
 
+#if MCX_RNG == 1
+    // Philox stream: unit = one Philox call j = iterations 4j .. 4j+3 (two Box-Muller pairs for the normal)
+    auto philox_sample = [&](u32 h_first, u32 h_second, u32 n_valid) {
+        // consumes two outputs = two iterations; n_valid in {1, 2} of them exist (i < L)
 #if MCX_DIST == MCX_DIST_NORMAL
+        float z0, z1;
+        mcx_box_muller(h_first, h_second, z0, z1);
+        mcx_accumulate(a.param1 + a.param2 * z0, is_tb, accA);
+        if (n_valid > 1u) mcx_accumulate(a.param1 + a.param2 * z1, is_tb, MCX_ACC_B);
+#else
+        mcx_accumulate(mcx_draw(h_first, a, cdf_tb), is_tb, accA);
+        if (n_valid > 1u) mcx_accumulate(mcx_draw(h_second, a, cdf_tb), is_tb, MCX_ACC_B);
+#endif
+    };
+    const u32 full_quads = a.loops_per_thread >> 2;          // calls whose four iterations all exist
+    const u32 e_full = u1 < full_quads ? u1 : full_quads;
+    u32 j = u0;
+    while (j < e_full) {
+        u32 blk_end = j + MCX_FLUSH / 2u;
+        blk_end = blk_end < e_full ? blk_end : e_full;
+        MCX_ZERO_ACC();
+        for (; j < blk_end; ++j) {
+            const McxU4 o = mcx_philox4x32_10(McxU4{idx, j, 0u, 0u}, a.seed, MCX_PHILOX_KEY1);
+            philox_sample(o.x, o.y, 2u);
+            philox_sample(o.z, o.w, 2u);
+        }
+        MCX_FLUSH_ACC();
+    }
+    if (active && u1 > full_quads) {                          // the last, partial call: 1..3 iterations left
+        const u32 rem = a.loops_per_thread - 4u * full_quads;
+        const McxU4 o = mcx_philox4x32_10(McxU4{idx, full_quads, 0u, 0u}, a.seed, MCX_PHILOX_KEY1);
+        MCX_ZERO_ACC();
+        philox_sample(o.x, o.y, rem >= 2u ? 2u : 1u);
+        if (rem == 3u) philox_sample(o.z, o.w, 1u);
+        MCX_FLUSH_ACC();
+    }
+#elif MCX_DIST == MCX_DIST_NORMAL
     // unit = Box-Muller pair j: iterations (2j, 2j+1), counters (4j, 4j+1) (distribution.rs:97-98)
     const u32 full_pairs = a.loops_per_thread >> 1;          // pairs whose second half is used
     const u32 e_full = u1 < full_pairs ? u1 : full_pairs;

@@ -43,12 +43,12 @@ int mcx_mcmc_dispatch_config(uint32_t n_chains, int64_t target_threads, mcx_disp
     return MCX_OK;
 }
 
-int mcx_shard_integrate(const mcx_dispatch* d, int dist_type, uint32_t rank, uint32_t world, mcx_shard* out) {
-    if (!d || !out) return mcx::fail(MCX_E_INVALID, "mcx_shard_integrate: null argument");
-    if (world == 0u || rank >= world) return mcx::fail(MCX_E_INVALID, "mcx_shard_integrate: rank/world out of range");
-    const uint32_t L = d->loops_per_thread;
-    // units per logical thread: iterations, or Box-Muller pairs for the normal sampler
-    const uint64_t units = dist_type == MCX_DIST_NORMAL ? ((uint64_t)L + 1ull) / 2ull : (uint64_t)L;
+int mcx_shard_units(const mcx_dispatch* d, uint32_t iterations_per_unit, uint32_t rank, uint32_t world, mcx_shard* out) {
+    if (!d || !out) return mcx::fail(MCX_E_INVALID, "mcx_shard_units: null argument");
+    if (world == 0u || rank >= world) return mcx::fail(MCX_E_INVALID, "mcx_shard_units: rank/world out of range");
+    if (iterations_per_unit == 0u) return mcx::fail(MCX_E_INVALID, "mcx_shard_units: iterations_per_unit must be positive");
+    const uint64_t L = d->loops_per_thread;
+    const uint64_t units = (L + iterations_per_unit - 1ull) / iterations_per_unit;
     if (units >= (uint64_t)world) {
         // split the iteration axis: every rank sees every logical idx, a contiguous unit range
         out->idx_begin = 0u;
@@ -65,6 +65,11 @@ int mcx_shard_integrate(const mcx_dispatch* d, int dist_type, uint32_t rank, uin
         out->unit_end = (uint32_t)units;
     }
     return MCX_OK;
+}
+
+int mcx_shard_integrate(const mcx_dispatch* d, int dist_type, uint32_t rank, uint32_t world, mcx_shard* out) {
+    // units per logical thread: iterations, or Box-Muller pairs for the normal sampler
+    return mcx_shard_units(d, dist_type == MCX_DIST_NORMAL ? 2u : 1u, rank, world, out);
 }
 
 int mcx_shard_chains(uint32_t total_chains, uint32_t rank, uint32_t world,

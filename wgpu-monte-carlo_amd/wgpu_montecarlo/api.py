@@ -136,16 +136,22 @@ class MonteCarloIntegrator:
             "fast" (also hardware sin/cos/tan) or "precise" (ocml + IEEE division everywhere).
         strict_reference_uniform: reproduce u = float(hash)*2^-32 on the closed interval [0,1]
             (reference behaviour, can produce log(0)); default False guards the end points.
+        rng: "pcg_ref" (default) is the reference's counter hash -- bit-exact sample indexing, but a 32-bit
+            counter space that is oversubscribed beyond ~4e9 uniforms per call; "philox" is Philox4x32-10 with a
+            128-bit counter (integrate / importance sampling; MCMC keeps the reference stream).
     """
 
     def __init__(self, target_threads: Optional[int] = None, device: Optional[int] = None, process_group=None,
-                 math: str = "default", strict_reference_uniform: bool = False):
+                 math: str = "default", strict_reference_uniform: bool = False, rng: str = "pcg_ref"):
         try:
             runtime.load()
         except ImportError:
             raise
         if math not in ("default", "fast", "precise"):
             raise ValueError("math must be 'default', 'fast' or 'precise'")
+        if rng not in runtime.RNG_CODES:
+            raise ValueError("rng must be 'pcg_ref' (the reference's stream) or 'philox'")
+        self._rng = runtime.RNG_CODES[rng]
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0")) if runtime.device_count() > 1 else 0
         self._engine = runtime.Engine(device)       # RuntimeError("Failed to initialize GPU: ...") without a GPU
@@ -228,7 +234,7 @@ class MonteCarloIntegrator:
         cdf = self._cdf_table(distribution)
         lds_ok = self._lds_bytes(cdf) <= _LDS_TABLE_BUDGET
         desc = runtime.make_desc(runtime.KIND_INTEGRATE, len(functions), code, guard_endpoints=self._guard,
-                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok)
+                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng)
         mod = self._engine.module(user_src, desc)
         rank, world = self._rank_world()
         values, n_eff = self._run(len(functions), lambda d_sums, stream: self._engine.integrate(
@@ -265,7 +271,7 @@ class MonteCarloIntegrator:
         desc = runtime.make_desc(runtime.KIND_INTEGRATE, len(functions), code, weight=True,
                                  p_table=p_table is not None, q_table=q_table is not None,
                                  guard_endpoints=self._guard, precise_sampler=self._precise_sampler,
-                                 tables_lds=lds_ok)
+                                 tables_lds=lds_ok, rng=self._rng)
         mod = self._engine.module(user_src, desc)
         rank, world = self._rank_world()
         values, n_eff = self._run(len(functions), lambda d_sums, stream: self._engine.integrate(
@@ -324,7 +330,7 @@ class MonteCarloIntegrator:
         cdf = self._cdf_table(distribution)
         lds_ok = self._lds_bytes(cdf) <= _LDS_TABLE_BUDGET
         desc = runtime.make_desc(runtime.KIND_INTEGRATE, len(functions), code, guard_endpoints=self._guard,
-                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok)
+                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng)
         return PreparedIntegrand(self, self._engine.module(user_src, desc), len(functions), p1, p2, cdf)
 
     def _meta(self, n_eff: int) -> dict:

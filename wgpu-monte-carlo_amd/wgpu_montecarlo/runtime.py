@@ -21,6 +21,8 @@ LIB_PATH = Path(os.environ.get("MCX_LIBRARY", str(_PKG_DIR / "libmcx.so")))
 DIST_UNIFORM, DIST_NORMAL, DIST_EXPONENTIAL, DIST_CUSTOM = 0, 1, 2, 3
 TABLE_CDF, TABLE_PDF, TABLE_LOGPDF = 0, 1, 2
 KIND_INTEGRATE, KIND_MCMC = 0, 1
+RNG_PCG_REF, RNG_PHILOX = 0, 1
+RNG_CODES = {"pcg_ref": RNG_PCG_REF, "philox": RNG_PHILOX}
 
 E_INVALID, E_RUNTIME, E_COMPILE, E_NODEVICE = -1, -2, -3, -4
 
@@ -40,7 +42,8 @@ class Shard(C.Structure):
 class ModuleDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("dist_type", C.c_int32), ("weight", C.c_int32),
                 ("p_table", C.c_int32), ("q_table", C.c_int32), ("guard_endpoints", C.c_int32),
-                ("precise_sampler", C.c_int32), ("block", C.c_int32), ("tables_lds", C.c_int32)]
+                ("precise_sampler", C.c_int32), ("block", C.c_int32), ("tables_lds", C.c_int32),
+                ("rng", C.c_int32)]
 
 
 class IntegrateParams(C.Structure):
@@ -59,7 +62,7 @@ class McmcParams(C.Structure):
 # every symbol include/mcx.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
     "mcx_version", "mcx_last_error", "mcx_hip_runtime", "mcx_dispatch_config", "mcx_mcmc_dispatch_config", "mcx_shard_integrate",
-    "mcx_shard_chains", "mcx_device_count", "mcx_engine_create", "mcx_engine_destroy", "mcx_engine_device",
+    "mcx_shard_units", "mcx_shard_chains", "mcx_device_count", "mcx_engine_create", "mcx_engine_destroy", "mcx_engine_device",
     "mcx_engine_last_kernel_ms", "mcx_engine_last_launch", "mcx_engine_set_target_threads", "mcx_module_build",
     "mcx_module_precompile", "mcx_module_source", "mcx_free", "mcx_module_release", "mcx_cache_dir",
     "mcx_table_create", "mcx_table_release", "mcx_table_info", "mcx_integrate", "mcx_integrate_device",
@@ -118,6 +121,7 @@ def load():
         L.mcx_dispatch_config.argtypes = [u64, i64, C.POINTER(Dispatch)]
         L.mcx_mcmc_dispatch_config.argtypes = [u32, i64, C.POINTER(Dispatch)]
         L.mcx_shard_integrate.argtypes = [C.POINTER(Dispatch), C.c_int, u32, u32, C.POINTER(Shard)]
+        L.mcx_shard_units.argtypes = [C.POINTER(Dispatch), u32, u32, u32, C.POINTER(Shard)]
         L.mcx_shard_chains.argtypes = [u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
         L.mcx_engine_create.argtypes = [C.c_int, C.POINTER(vp)]
         L.mcx_engine_destroy.argtypes = [vp]
@@ -179,6 +183,12 @@ def shard_integrate(d: Dispatch, dist_type: int, rank: int, world: int) -> Shard
     return s
 
 
+def shard_units(d: Dispatch, iterations_per_unit: int, rank: int, world: int) -> Shard:
+    s = Shard()
+    check(load().mcx_shard_units(C.byref(d), int(iterations_per_unit), int(rank), int(world), C.byref(s)))
+    return s
+
+
 def shard_chains(total_chains: int, rank: int, world: int):
     b, n = C.c_uint32(0), C.c_uint32(0)
     check(load().mcx_shard_chains(int(total_chains), int(rank), int(world), C.byref(b), C.byref(n)))
@@ -187,11 +197,11 @@ def shard_chains(total_chains: int, rank: int, world: int):
 
 def make_desc(kind: int, k: int, dist_type: int, weight: bool = False, p_table: bool = False,
               q_table: bool = False, guard_endpoints: bool = True, precise_sampler: bool = False,
-              block: int = 0, tables_lds: bool = True) -> ModuleDesc:
+              block: int = 0, tables_lds: bool = True, rng: int = 0) -> ModuleDesc:
     if not block and os.environ.get("MCX_BLOCK"):        # tuning knob
         block = int(os.environ["MCX_BLOCK"])
     return ModuleDesc(kind, k, dist_type, int(weight), int(p_table), int(q_table), int(guard_endpoints),
-                      int(precise_sampler), int(block), int(tables_lds))
+                      int(precise_sampler), int(block), int(tables_lds), int(rng))
 
 
 def module_source(user_src: str, desc: ModuleDesc) -> str:
