@@ -108,6 +108,9 @@ def main():
     from wgpu_montecarlo import Distribution, MonteCarloIntegrator
 
     integ = MonteCarloIntegrator(device=local_rank, rng=args.rng)
+    from wgpu_montecarlo import runtime as _rt
+
+    integ_runtime = _rt.hip_runtime()
     if args.target_phys:
         integ._engine.set_target_threads(args.target_phys)
     prepared = integ.prepare_integrate(moment_functions(), Distribution.normal(0.0, 1.0))
@@ -192,6 +195,7 @@ def main():
                                 f"sum all-reduce of {K} f64 per step") if world > 1 else "single GPU",
                 "accumulate": "f32 registers per 128 pairs -> f64",
                 "rng": args.rng,
+                "hip_runtime": integ_runtime,
             },
             "abs_err_vs_truth": abs_err.max(axis=0).tolist(),
             "three_sigma": three_sigma.tolist(),

@@ -66,4 +66,36 @@ const HipApi* hip_api(const char** why) {
     return &g_api;
 }
 
+static HiprtcApi g_rtc;
+static bool g_rtc_ok = false;
+static std::string g_rtc_why;
+static std::once_flag g_rtc_once;
+
+const HiprtcApi* hiprtc_api(const char** why) {
+    std::call_once(g_rtc_once, [] {
+        static std::string name;
+        void* lib = nullptr;
+        const char* env = getenv("MCX_HIPRTC");
+        for (const char* cand : {env ? env : "", "/opt/rocm/lib/libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so", "libhiprtc.so.7",
+                                 "libhiprtc.so"}) {
+            if (!*cand) continue;
+            if ((lib = dlopen(cand, RTLD_NOW | RTLD_LOCAL))) { name = cand; break; }
+        }
+        if (!lib) { g_rtc_why = std::string("hiprtc could not be loaded: ") + (dlerror() ? dlerror() : ""); return; }
+        HiprtcApi& a = g_rtc;
+        std::string& w = g_rtc_why;
+        g_rtc_ok = bind(lib, "hiprtcCreateProgram", &a.CreateProgram, &w) && bind(lib, "hiprtcCompileProgram", &a.CompileProgram, &w) &&
+                   bind(lib, "hiprtcGetProgramLogSize", &a.GetProgramLogSize, &w) && bind(lib, "hiprtcGetProgramLog", &a.GetProgramLog, &w) &&
+                   bind(lib, "hiprtcGetCodeSize", &a.GetCodeSize, &w) && bind(lib, "hiprtcGetCode", &a.GetCode, &w) &&
+                   bind(lib, "hiprtcDestroyProgram", &a.DestroyProgram, &w) && bind(lib, "hiprtcVersion", &a.Version, &w) &&
+                   bind(lib, "hiprtcGetErrorString", &a.GetErrorString, &w);
+        a.library = name.c_str();
+    });
+    if (!g_rtc_ok) {
+        if (why) *why = g_rtc_why.c_str();
+        return nullptr;
+    }
+    return &g_rtc;
+}
+
 }  // namespace mcx

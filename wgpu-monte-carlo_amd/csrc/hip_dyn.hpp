@@ -8,6 +8,7 @@
 // wgpu_montecarlo/runtime.py), else loads MCX_HIP_RUNTIME, else the system runtime.
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <hip/hiprtc.h>
 
 namespace mcx {
 
@@ -41,5 +42,22 @@ struct HipApi {
 
 // Bound on first use; nullptr (and an error text in `why`) if no HIP runtime can be loaded.
 const HipApi* hip_api(const char** why = nullptr);
+
+// hiprtc is bound the same way, but to ONE fixed compiler: the system ROCm's (MCX_HIPRTC overrides). torch
+// ships a libhiprtc.so.7 of an older ROCm under the same soname; resolving by soname would make the compiler
+// (and the code-object cache key) depend on whether torch was imported first.
+struct HiprtcApi {
+    hiprtcResult (*CreateProgram)(hiprtcProgram*, const char*, const char*, int, const char**, const char**);
+    hiprtcResult (*CompileProgram)(hiprtcProgram, int, const char**);
+    hiprtcResult (*GetProgramLogSize)(hiprtcProgram, size_t*);
+    hiprtcResult (*GetProgramLog)(hiprtcProgram, char*);
+    hiprtcResult (*GetCodeSize)(hiprtcProgram, size_t*);
+    hiprtcResult (*GetCode)(hiprtcProgram, char*);
+    hiprtcResult (*DestroyProgram)(hiprtcProgram*);
+    hiprtcResult (*Version)(int*, int*);
+    const char* (*GetErrorString)(hiprtcResult);
+    const char* library;
+};
+const HiprtcApi* hiprtc_api(const char** why = nullptr);
 
 }  // namespace mcx
