@@ -1,0 +1,69 @@
+/* cabi_client.c -- a plain-C client of libmcx.so (no Python, no torch): what a foreign-language binding of the
+ * reference (cgo / JNI / Rust FFI) would do. Built and run by tests/test_gpu_cabi_client.py.
+ *
+ *   gcc -O2 -I include tests/cabi_client.c -o cabi_client -ldl
+ *   ./cabi_client path/to/libmcx.so
+ *
+ * Prints "OK ..." lines; exits non-zero on any mismatch. Without a GPU it stops after the planning checks
+ * with exit code 3.
+ */
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "mcx.h"
+
+#define LOAD(name) __typeof__(name)* p_##name = (__typeof__(name)*)dlsym(lib, #name); if (!p_##name) { fprintf(stderr, "missing %s\n", #name); return 2; }
+
+static const char* USER_SRC =
+    "MCX_DEV float user_func_0(float x) { return x; }\n"
+    "MCX_DEV float user_func_1(float x) { return x * x; }\n"
+    "MCX_DEV float user_func_2(float x) { return x > 1.0f ? 1.0f : 0.0f; }\n";
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: %s libmcx.so\n", argv[0]); return 2; }
+    void* lib = dlopen(argv[1], RTLD_NOW);
+    if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+    LOAD(mcx_version) LOAD(mcx_last_error) LOAD(mcx_dispatch_config) LOAD(mcx_mcmc_dispatch_config)
+    LOAD(mcx_shard_integrate) LOAD(mcx_device_count) LOAD(mcx_engine_create) LOAD(mcx_engine_destroy)
+    LOAD(mcx_module_build) LOAD(mcx_module_release) LOAD(mcx_integrate) LOAD(mcx_engine_last_kernel_ms)
+    LOAD(mcx_hip_runtime)
+
+    printf("OK version %s\n", p_mcx_version());
+    mcx_dispatch d;
+    if (p_mcx_dispatch_config(1000000000ull, 0, &d) || d.total_threads != 65536u || d.loops_per_thread != 15259u) return 1;
+    if (p_mcx_mcmc_dispatch_config(1u, 0, &d) || d.total_threads != 256u) return 1;
+    if (p_mcx_dispatch_config(1000000ull, 0, &d)) return 1;
+    mcx_shard s0, s1;
+    if (p_mcx_shard_integrate(&d, MCX_DIST_NORMAL, 0, 2, &s0) || p_mcx_shard_integrate(&d, MCX_DIST_NORMAL, 1, 2, &s1)) return 1;
+    if (s0.unit_begin != 0u || s0.unit_end != s1.unit_begin || s1.unit_end != 8u) return 1;
+    printf("OK planning T=%u L=%u\n", d.total_threads, d.loops_per_thread);
+
+    if (p_mcx_device_count() < 1) { printf("no GPU visible: stopping after the planning checks\n"); return 3; }
+    mcx_engine* e = NULL;
+    if (p_mcx_engine_create(0, &e)) { fprintf(stderr, "engine: %s\n", p_mcx_last_error()); return 1; }
+    printf("OK engine on %s\n", p_mcx_hip_runtime());
+    mcx_module_desc desc;
+    memset(&desc, 0, sizeof desc);
+    desc.kind = MCX_KIND_INTEGRATE; desc.k = 3; desc.dist_type = MCX_DIST_NORMAL; desc.guard_endpoints = 1; desc.tables_lds = 1;
+    mcx_module* m = NULL;
+    if (p_mcx_module_build(e, USER_SRC, &desc, &m)) { fprintf(stderr, "module: %s\n", p_mcx_last_error()); return 1; }
+    mcx_integrate_params p;
+    memset(&p, 0, sizeof p);
+    p.n_samples = 100000000ull; p.seed = 42u; p.param1 = 0.0f; p.param2 = 1.0f; p.world = 1u;
+    double sums[3]; uint64_t n_eff = 0;
+    if (p_mcx_integrate(e, m, &p, sums, &n_eff)) { fprintf(stderr, "integrate: %s\n", p_mcx_last_error()); return 1; }
+    double mean = sums[0] / (double)n_eff, second = sums[1] / (double)n_eff, tail = sums[2] / (double)n_eff;
+    printf("OK integrate n_eff=%llu E[x]=%.6f E[x^2]=%.6f P(x>1)=%.6f kernel_ms=%.3f\n", (unsigned long long)n_eff, mean, second,
+           tail, p_mcx_engine_last_kernel_ms(e));
+    if (n_eff != 65536ull * 1526ull) return 1;
+    if (fabs(mean) > 5e-4 || fabs(second - 1.0) > 1e-3 || fabs(tail - 0.158655) > 3e-4) return 1;
+    desc.k = 0;                                                     /* src/lib.rs:61-65 */
+    mcx_module* bad = NULL;
+    if (p_mcx_module_build(e, USER_SRC, &desc, &bad) != MCX_E_INVALID || !strstr(p_mcx_last_error(), "At least one function")) return 1;
+    printf("OK errors: %s\n", p_mcx_last_error());
+    p_mcx_module_release(m);
+    p_mcx_engine_destroy(e);
+    return 0;
+}

@@ -344,3 +344,26 @@ def test_philox_shards_and_full_size():
     res = mc.integrate(MOMENTS, Distribution.normal(0.0, 1.0), n_samples=10**9, seed=42)
     sigma = np.sqrt(np.array([1.0, 2.0, 15.0, 96.0]) / res.meta["n_eff"])
     assert np.all(np.abs(res.values - [0, 1, 0, 3]) < 3.5 * sigma), res.values
+
+
+def test_large_tables_fall_back_to_global_memory_and_capped_search(integrator):
+    """Tables beyond the LDS budget are read from HBM/L2 (tables_lds = 0). With n > 4096 points the reference's
+    12-step CDF search is NOT an exact lower bound any more: the capped search itself must be reproduced."""
+    from wgpu_montecarlo import Distribution
+
+    proposal = Distribution.from_pdf(lambda x: math.exp(-abs(x)) / 2, support=(-12, 12), table_size=6000)
+    xt = np.linspace(-6, 6, 5000)
+    target = Distribution.from_pdf_table(xt, np.exp(-0.5 * xt * xt) / np.sqrt(2 * np.pi))
+    res = integrator.integrate_importance_sampling([lambda x: x, lambda x: x**2], target, proposal, n_samples=1_000_000, seed=4)
+    assert res.meta["lds_bytes"] == 0                      # (6000 + 5000 + 6000) * 8 B > 62 KiB
+    ref = oracle.integrate([(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2)], oracle.CUSTOM, n_samples=1_000_000, seed=4, guard=1,
+                           cdf_table=proposal._cdf_table, x_table=proposal._x_table,
+                           p=(oracle.PDF_TABLE, target._x_table, target._pdf_table),
+                           q=(oracle.PDF_TABLE, *proposal.get_or_compute_pdf_table()))
+    ok, msg = close(res.values, ref["sums"] / ref["n_eff"])
+    assert ok, msg
+    plain = integrator.integrate([lambda x: x, lambda x: x**2], proposal, n_samples=1_000_000, seed=4)
+    ref = oracle.integrate([(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2)], oracle.CUSTOM, n_samples=1_000_000, seed=4, guard=1,
+                           cdf_table=proposal._cdf_table, x_table=proposal._x_table)
+    ok, msg = close(plain.values, ref["sums"] / ref["n_eff"], tol=2e-6)
+    assert ok, msg

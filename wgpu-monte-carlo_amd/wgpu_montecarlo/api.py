@@ -143,10 +143,7 @@ class MonteCarloIntegrator:
 
     def __init__(self, target_threads: Optional[int] = None, device: Optional[int] = None, process_group=None,
                  math: str = "default", strict_reference_uniform: bool = False, rng: str = "pcg_ref"):
-        try:
-            runtime.load()
-        except ImportError:
-            raise
+        runtime.load()                               # ImportError if libmcx.so has not been built
         if math not in ("default", "fast", "precise"):
             raise ValueError("math must be 'default', 'fast' or 'precise'")
         if rng not in runtime.RNG_CODES:
@@ -204,7 +201,8 @@ class MonteCarloIntegrator:
         g = self._group
         if g is None or g.world < 2:
             sums, n_eff = call(None, None)
-            return sums / float(n_eff), n_eff
+            with np.errstate(divide="ignore", invalid="ignore"):      # n_samples = 0 -> 0/0 = NaN, like the reference
+                return sums / float(n_eff), n_eff
         if g.backend == "nccl":
             import torch
 
