@@ -346,16 +346,18 @@ def test_philox_shards_and_full_size():
     assert np.all(np.abs(res.values - [0, 1, 0, 3]) < 3.5 * sigma), res.values
 
 
-def test_large_tables_fall_back_to_global_memory_and_capped_search(integrator):
-    """Tables beyond the LDS budget are read from HBM/L2 (tables_lds = 0). With n > 4096 points the reference's
-    12-step CDF search is NOT an exact lower bound any more: the capped search itself must be reproduced."""
+@pytest.mark.parametrize("n_prop,n_tgt,in_lds", [(6000, 5000, True), (9000, 7000, False)])
+def test_large_tables_and_capped_search(integrator, n_prop, n_tgt, in_lds):
+    """Tables up to 156 KiB are staged in LDS (one 1024-thread workgroup per CU); beyond that they are read from
+    HBM/L2 (tables_lds = 0). With n > 4096 points the reference's 12-step CDF search is NOT an exact lower bound
+    any more: the capped search itself must be reproduced."""
     from wgpu_montecarlo import Distribution
 
-    proposal = Distribution.from_pdf(lambda x: math.exp(-abs(x)) / 2, support=(-12, 12), table_size=6000)
-    xt = np.linspace(-6, 6, 5000)
+    proposal = Distribution.from_pdf(lambda x: math.exp(-abs(x)) / 2, support=(-12, 12), table_size=n_prop)
+    xt = np.linspace(-6, 6, n_tgt)
     target = Distribution.from_pdf_table(xt, np.exp(-0.5 * xt * xt) / np.sqrt(2 * np.pi))
     res = integrator.integrate_importance_sampling([lambda x: x, lambda x: x**2], target, proposal, n_samples=1_000_000, seed=4)
-    assert res.meta["lds_bytes"] == 0                      # (6000 + 5000 + 6000) * 8 B > 62 KiB
+    assert res.meta["lds_bytes"] == ((2 * n_prop + n_tgt) * 8 if in_lds else 0)
     ref = oracle.integrate([(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2)], oracle.CUSTOM, n_samples=1_000_000, seed=4, guard=1,
                            cdf_table=proposal._cdf_table, x_table=proposal._x_table,
                            p=(oracle.PDF_TABLE, target._x_table, target._pdf_table),

@@ -25,8 +25,8 @@ from .frontend import TranspilerError
 
 FunctionLike = Union[Callable, str]
 
-# LDS budget for staged tables (csrc/mcx_runtime.cpp MCX_LDS_DYNAMIC_MAX)
-_LDS_TABLE_BUDGET = 64 * 1024 - 2048
+# LDS budget for staged tables (csrc/mcx_runtime.cpp lds_dynamic_max(): 160 KiB per CU minus static scratch)
+_LDS_TABLE_BUDGET = 156 * 1024
 
 
 class IntegrationResult:
