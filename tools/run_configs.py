@@ -116,18 +116,7 @@ def main():
                wall, steps, "MH steps/s")
     if not only or "C5" in only:
         n = int(1e10 * args.scale)
-        # 32 lambdas with recoverable source: a generated module
-        import importlib.util
-        import tempfile
-
-        src = "\n".join(f"f{k} = lambda x: x**{k}" for k in range(1, 33))
-        with tempfile.NamedTemporaryFile("w", suffix="_mcx_k32.py", delete=False) as fh:
-            fh.write(src + "\n")
-            path = fh.name
-        spec = importlib.util.spec_from_file_location("mcx_k32", path)
-        mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
-        fns = [getattr(mod, f"f{k}") for k in range(1, 33)]
+        fns = [lambda x, k=k: x**k for k in range(1, 33)]      # bound defaults -> constants -> shared multiply chain
         dist = Distribution.beta(2.0, 5.0)
         res, wall = timed(lambda: integ.integrate(fns, dist, n_samples=n), args.repeat)
 

@@ -82,7 +82,7 @@ def functions_to_hip(functions: Sequence[FunctionLike], math="default") -> str:
     parts = [emit_hip.prelude()]
     for i, fn in enumerate(functions):
         if callable(fn):
-            ir_fn = frontend.lower(fn)
+            ir_fn = frontend.lower(fn, bind_defaults=True)
             name = f"user_func_{i}"
             key = (getattr(fn, "__code__", None), name, math, tuple(ir_fn.consts.items()))
             parts.append(_emit_cached(key, lambda: emit_hip.emit_function(ir_fn, name, math)))

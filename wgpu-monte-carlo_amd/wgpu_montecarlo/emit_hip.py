@@ -103,7 +103,8 @@ def _mode(math) -> str:
 
 
 class _HipPrinter:
-    def __init__(self, math) -> None:
+    def __init__(self, math, consts=None) -> None:
+        self.consts = consts or {}
         self.mode = _mode(math)
         self.table = {"precise": {}, "default": _NATIVE_FUNCS, "fast": _FAST_FUNCS}[self.mode]
 
@@ -127,8 +128,13 @@ class _HipPrinter:
             base = self.expr(node.base)
             exponent = node.exponent
             sign = 1.0
-            if isinstance(exponent, ir.Unary) and exponent.op == "-" and isinstance(exponent.operand, ir.Num):
+            if isinstance(exponent, ir.Unary) and exponent.op == "-" and isinstance(exponent.operand, (ir.Num, ir.Var)):
                 exponent, sign = exponent.operand, -1.0
+            if isinstance(exponent, ir.Var) and exponent.name in self.consts:
+                # a captured constant (closure / global / bound default) is as good as a literal
+                exponent = ir.Num(self.consts[exponent.name])
+                if exponent.value < 0:
+                    exponent, sign = ir.Num(-exponent.value), -sign
             if isinstance(exponent, ir.Num) and float(exponent.value).is_integer() and 0 <= exponent.value <= 64:
                 n = int(exponent.value)
                 chain = f"McxPowI<{n}>::of({base})"
@@ -198,7 +204,7 @@ def _assigned_names(stmts, acc: List[str]) -> None:
 
 def emit_function(fn: ir.Function, name: str, math="default") -> str:
     """One IR function as a HIP device function called `name` (math: "precise" | "default" | "fast")."""
-    printer = _HipPrinter(math)
+    printer = _HipPrinter(math, fn.consts)
     params = ", ".join(f"float {_ident(p)}" for p in fn.params)
     lines = [f"MCX_DEV float {name}({params}) {{"]
     for cname, cvalue in fn.consts.items():

@@ -527,8 +527,12 @@ _LOWER_CACHE: Dict[object, object] = {}       # code object -> _Lowered | Transp
 _LOWER_CACHE_LIMIT = 4096
 
 
-def lower(func: Callable) -> Function:
+def lower(func: Callable, bind_defaults: bool = False) -> Function:
     """Lower a Python function or lambda to the IR (raises TranspilerError outside the subset).
+
+    bind_defaults=True (the HIP path) turns trailing parameters that have default values into captured
+    constants -- `[lambda x, k=k: x**k for k in range(1, 5)]` works -- where the reference emits a
+    two-parameter WGSL function that fails at shader compilation.
 
     The structural part (source recovery, parsing, import analysis, IR) is memoised per code object -- the
     reference repeats it on every call (transpiler.py:160-182, 369-403); free variables are re-captured
@@ -553,7 +557,23 @@ def lower(func: Callable) -> Function:
     low = _Lowering()
     low.imports, low.module_aliases = rec.imports, rec.module_aliases
     consts = low.capture(func, set(rec.params), rec.used, rec.assigned)
-    return Function(rec.name, list(rec.params), consts, rec.body)
+    params = list(rec.params)
+    defaults = getattr(func, "__defaults__", None) or ()
+    if bind_defaults and defaults and len(params) > 1:
+        bound = params[max(1, len(params) - len(defaults)):]
+        values = defaults[len(defaults) - len(bound):]
+        for name, value in zip(bound, values):
+            if isinstance(value, bool):
+                consts[name] = 1.0 if value else 0.0
+            elif isinstance(value, (int, float)):
+                consts[name] = float(value)
+            else:
+                raise TranspilerError(
+                    f"Unsupported external variable type for '{name}': {type(value).__name__}. "
+                    f"Only int, float, and bool are supported."
+                )
+        params = params[: len(params) - len(bound)]
+    return Function(rec.name, params, consts, rec.body)
 
 
 def _lower_structure(func: Callable) -> _Lowered:
