@@ -200,6 +200,7 @@ def main():
             "abs_err_vs_truth": abs_err.max(axis=0).tolist(),
             "three_sigma": three_sigma.tolist(),
             "worst_err_over_3sigma": worst_ratio,
+            "frac_within_3sigma": float((abs_err <= three_sigma).mean()),
             "per_gpu_samples_per_s": value / world,
             "api_call_ms": api_ms,
             "api_values": res.values.tolist(),
