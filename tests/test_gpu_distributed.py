@@ -93,3 +93,47 @@ def test_device_resident_launch_follows_torch_streams(integrator):
     for got in (copy0, copy1, out[2]):
         assert np.array_equal(got.cpu().numpy() / float(n_eff), want.values)
     assert np.array_equal(prepared.run(50_000_000, 3).values, want.values)
+
+
+_RCCL_SCRIPT = r"""
+import os, sys
+sys.path[:0] = [%(pkg)r, %(root)r]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%(port)r, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from wgpu_montecarlo import Distribution, MonteCarloIntegrator, distributed, runtime
+mc = MonteCarloIntegrator(device=0)
+assert "already loaded" in runtime.hip_runtime(), runtime.hip_runtime()      # torch's HIP runtime instance
+f1 = lambda x: x
+f2 = lambda x: x**2
+prepared = mc.prepare_integrate([f1, f2], Distribution.normal(0.0, 1.0))
+want = mc.integrate([f1, f2], Distribution.normal(0.0, 1.0), n_samples=200_000_000, seed=11)
+group = distributed.Group()
+assert (group.backend, group.world) == ("nccl", 1)
+out = torch.zeros(8, 2, dtype=torch.float64, device="cuda")
+works = []
+for i in range(8):                                   # kernel i -> RCCL all-reduce i (async) -> kernel i+1 overlaps it
+    n_eff = prepared.launch(200_000_000, 11, out[i])
+    works.append(distributed.all_reduce_device(group, out[i], async_op=True))
+for w in works:
+    w.wait()
+torch.cuda.synchronize()
+got = out.cpu().numpy() / float(n_eff)
+assert all(np.array_equal(row, want.values) for row in got), (got, want.values)
+host = distributed.all_reduce_host(group, np.array([1.5, 2.5]))
+assert np.array_equal(host, [1.5, 2.5])
+dist.destroy_process_group()
+print("RCCL-OK")
+"""
+
+
+def test_rccl_all_reduce_is_ordered_after_our_kernels(tmp_path):
+    """A real RCCL communicator (1 rank: the box has one GPU) in the same process as libmcx: the collective is
+    enqueued behind our kernels on torch's stream and both use ONE HIP runtime instance."""
+    import subprocess
+
+    script = tmp_path / "rccl_one_rank.py"          # a file: lambdas need recoverable source
+    script.write_text(_RCCL_SCRIPT % dict(pkg=str(ROOT / "wgpu-monte-carlo_amd"), root=str(ROOT), port=str(_free_port())))
+    res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "RCCL-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
