@@ -127,6 +127,8 @@ typedef struct mcx_module_desc {
     int32_t rng;               /* 0 (default): the reference's PCG counter hash (parity stream);
                                 * 1: Philox4x32-10, counter (idx, i/4, 0, 0), key (seed, 'MCX1') -- opt-in for runs that
                                 * draw more than ~2^32 uniforms (K1/K2 only) */
+    int32_t second_moments;    /* 1: rows k..2k-1 of the result hold the sums of (f_i * w)^2 (standard errors); the
+                                * result then has 2k rows (integrate / importance sampling only) */
 } mcx_module_desc;
 
 #define MCX_RNG_PCG_REF 0

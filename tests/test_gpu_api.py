@@ -191,3 +191,20 @@ def test_math_modes_agree(mc):
             for m in ("precise", "default", "fast")}
     assert np.allclose(vals["default"], vals["precise"], atol=2e-6)
     assert np.allclose(vals["fast"], vals["precise"], atol=2e-5)
+
+
+def test_std_error_output():
+    """std_error=True (extension): sum (f w)^2 accumulated in the same pass; standard errors match theory."""
+    from wgpu_montecarlo import MonteCarloIntegrator
+
+    mc = MonteCarloIntegrator(std_error=True)
+    plain = MonteCarloIntegrator()
+    fns = [lambda x: x, lambda x: x**2, lambda x: x**3, lambda x: x**4]
+    r = mc.integrate(fns, D().normal(0.0, 1.0), n_samples=10_000_000, seed=42)
+    assert np.array_equal(r.values, plain.integrate(fns, D().normal(0.0, 1.0), n_samples=10_000_000, seed=42).values)
+    want = np.sqrt(np.array([1.0, 2.0, 15.0, 96.0]) / r.meta["n_eff"])
+    assert np.allclose(r.meta["std_error"], want, rtol=0.02)
+    assert np.all(np.abs(r.values - [0, 1, 0, 3]) < 4 * r.meta["std_error"])
+    r = mc.integrate_importance_sampling([lambda x: x > 3.0], D().normal(0.0, 1.0), D().normal(3.5, 1.0), n_samples=5_000_000)
+    assert abs(r.values[0] - 0.0013499) < 4 * r.meta["std_error"][0] and r.meta["std_error"][0] < 3e-6
+    assert "std_error" not in plain.integrate(fns, D().normal(0.0, 1.0), n_samples=100_000).meta

@@ -139,16 +139,20 @@ class MonteCarloIntegrator:
         rng: "pcg_ref" (default) is the reference's counter hash -- bit-exact sample indexing, but a 32-bit
             counter space that is oversubscribed beyond ~4e9 uniforms per call; "philox" is Philox4x32-10 with a
             128-bit counter (integrate / importance sampling; MCMC keeps the reference stream).
+        std_error: also accumulate sum (f_k w)^2 in the same pass; integrate / importance-sampling results then
+            carry result.meta["std_error"][k] = sqrt((E[(f w)^2] - E[f w]^2) / N_eff) (extension; K <= 32).
     """
 
     def __init__(self, target_threads: Optional[int] = None, device: Optional[int] = None, process_group=None,
-                 math: str = "default", strict_reference_uniform: bool = False, rng: str = "pcg_ref"):
+                 math: str = "default", strict_reference_uniform: bool = False, rng: str = "pcg_ref",
+                 std_error: bool = False):
         runtime.load()                               # ImportError if libmcx.so has not been built
         if math not in ("default", "fast", "precise"):
             raise ValueError("math must be 'default', 'fast' or 'precise'")
         if rng not in runtime.RNG_CODES:
             raise ValueError("rng must be 'pcg_ref' (the reference's stream) or 'philox'")
         self._rng = runtime.RNG_CODES[rng]
+        self._std_error = bool(std_error)
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0")) if runtime.device_count() > 1 else 0
         self._engine = runtime.Engine(device)       # RuntimeError("Failed to initialize GPU: ...") without a GPU
@@ -231,14 +235,16 @@ class MonteCarloIntegrator:
         code, p1, p2 = _dist_params(distribution)
         cdf = self._cdf_table(distribution)
         lds_ok = self._lds_bytes(cdf) <= _LDS_TABLE_BUDGET
-        desc = runtime.make_desc(runtime.KIND_INTEGRATE, len(functions), code, guard_endpoints=self._guard,
-                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng)
+        k = len(functions)
+        desc = runtime.make_desc(runtime.KIND_INTEGRATE, k, code, guard_endpoints=self._guard,
+                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng,
+                                 second_moments=self._std_error)
         mod = self._engine.module(user_src, desc)
         rank, world = self._rank_world()
-        values, n_eff = self._run(len(functions), lambda d_sums, stream: self._engine.integrate(
+        values, n_eff = self._run(k * (2 if self._std_error else 1), lambda d_sums, stream: self._engine.integrate(
             mod, n_samples, seed, p1, p2, self._target_threads, cdf=cdf, rank=rank, world=world,
             d_sums=d_sums, stream=stream))
-        return IntegrationResult(values, n_samples, len(functions), self._meta(n_eff))
+        return IntegrationResult(values[:k], n_samples, k, self._meta(n_eff, values, k))
 
     # ---- K2 ----------------------------------------------------------------------------------------
     def integrate_importance_sampling(self, functions: List[FunctionLike], target_distribution: Distribution,
@@ -266,16 +272,17 @@ class MonteCarloIntegrator:
         else:
             user_src += "\n\n" + q_src
         lds_ok = self._lds_bytes(cdf, p_table, q_table) <= _LDS_TABLE_BUDGET
-        desc = runtime.make_desc(runtime.KIND_INTEGRATE, len(functions), code, weight=True,
+        k = len(functions)
+        desc = runtime.make_desc(runtime.KIND_INTEGRATE, k, code, weight=True,
                                  p_table=p_table is not None, q_table=q_table is not None,
                                  guard_endpoints=self._guard, precise_sampler=self._precise_sampler,
-                                 tables_lds=lds_ok, rng=self._rng)
+                                 tables_lds=lds_ok, rng=self._rng, second_moments=self._std_error)
         mod = self._engine.module(user_src, desc)
         rank, world = self._rank_world()
-        values, n_eff = self._run(len(functions), lambda d_sums, stream: self._engine.integrate(
+        values, n_eff = self._run(k * (2 if self._std_error else 1), lambda d_sums, stream: self._engine.integrate(
             mod, n_samples, seed, p1, p2, self._target_threads, cdf=cdf, target_pdf=p_table,
             proposal_pdf=q_table, rank=rank, world=world, d_sums=d_sums, stream=stream))
-        return IntegrationResult(values, n_samples, len(functions), self._meta(n_eff))
+        return IntegrationResult(values[:k], n_samples, k, self._meta(n_eff, values, k))
 
     # ---- K3 ----------------------------------------------------------------------------------------
     def integrate_mcmc(self, functions: List[FunctionLike], target_distribution: Distribution,
@@ -331,11 +338,16 @@ class MonteCarloIntegrator:
                                  precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng)
         return PreparedIntegrand(self, self._engine.module(user_src, desc), len(functions), p1, p2, cdf)
 
-    def _meta(self, n_eff: int) -> dict:
+    def _meta(self, n_eff: int, values=None, k: int = 0) -> dict:
         launch = self._engine.last_launch()
         rank, world = self._rank_world()
-        return dict(n_eff=n_eff, kernel_ms=self._engine.last_kernel_ms(), n_blocks=launch["n_blocks"],
+        meta = dict(n_eff=n_eff, kernel_ms=self._engine.last_kernel_ms(), n_blocks=launch["n_blocks"],
                     block=launch["block"], lds_bytes=launch["lds_bytes"], rank=rank, world=world)
+        if values is not None and len(values) == 2 * k and k:
+            with np.errstate(invalid="ignore", divide="ignore"):
+                var = np.maximum(values[k:] - values[:k] ** 2, 0.0)
+                meta["std_error"] = np.sqrt(var / float(n_eff))
+        return meta
 
 
 class PreparedIntegrand:

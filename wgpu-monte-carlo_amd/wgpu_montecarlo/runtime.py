@@ -43,7 +43,7 @@ class ModuleDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("dist_type", C.c_int32), ("weight", C.c_int32),
                 ("p_table", C.c_int32), ("q_table", C.c_int32), ("guard_endpoints", C.c_int32),
                 ("precise_sampler", C.c_int32), ("block", C.c_int32), ("tables_lds", C.c_int32),
-                ("rng", C.c_int32)]
+                ("rng", C.c_int32), ("second_moments", C.c_int32)]
 
 
 class IntegrateParams(C.Structure):
@@ -197,11 +197,11 @@ def shard_chains(total_chains: int, rank: int, world: int):
 
 def make_desc(kind: int, k: int, dist_type: int, weight: bool = False, p_table: bool = False,
               q_table: bool = False, guard_endpoints: bool = True, precise_sampler: bool = False,
-              block: int = 0, tables_lds: bool = True, rng: int = 0) -> ModuleDesc:
+              block: int = 0, tables_lds: bool = True, rng: int = 0, second_moments: bool = False) -> ModuleDesc:
     if not block and os.environ.get("MCX_BLOCK"):        # tuning knob
         block = int(os.environ["MCX_BLOCK"])
     return ModuleDesc(kind, k, dist_type, int(weight), int(p_table), int(q_table), int(guard_endpoints),
-                      int(precise_sampler), int(block), int(tables_lds), int(rng))
+                      int(precise_sampler), int(block), int(tables_lds), int(rng), int(second_moments))
 
 
 def module_source(user_src: str, desc: ModuleDesc) -> str:
@@ -338,7 +338,7 @@ class Engine:
             check(load().mcx_integrate_device(self._h, mod._h, C.byref(p), C.c_void_p(d_sums),
                                               _stream_arg(stream), C.byref(n_eff)))
             return None, int(n_eff.value)
-        sums = np.zeros(mod.desc.k, dtype=np.float64)
+        sums = np.zeros(mod.desc.k * (2 if mod.desc.second_moments else 1), dtype=np.float64)
         check(load().mcx_integrate(self._h, mod._h, C.byref(p), sums.ctypes.data_as(C.POINTER(C.c_double)),
                                    C.byref(n_eff)))
         return sums, int(n_eff.value)
