@@ -1,0 +1,80 @@
+"""Randomised parity sweep (fixed seeds): small odd geometries of the logical grid and of the physical launch,
+every sampler, random shards and physical-thread targets, against the oracle on the same streams."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+F = [lambda x: x, lambda x: x * x, lambda x: math.cos(x)]
+
+
+def _expected(xs):
+    xs = xs.astype(np.float64)
+    return np.array([xs.sum(), (xs * xs).sum(), np.cos(xs).sum()])
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_geometry_k1(case):
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo import runtime as rt
+    from wgpu_montecarlo.api import MonteCarloIntegrator, functions_to_hip
+
+    rng = np.random.default_rng(1000 + case)
+    target = int(rng.choice([1, 255, 256, 257, 700, 1000, 4096, 5000, 65536]))
+    n = int(rng.choice([1, 2, 3, 5, 17, 255, 1001, 4097, 99_999, 300_001, 1_000_003]))
+    if target * 1 > 65536 and n > 300_001:
+        n = 300_001
+    seed = int(rng.integers(0, 2**32))
+    kind = int(rng.integers(0, 4))
+    beta = Distribution.beta(float(rng.uniform(1.5, 4)), float(rng.uniform(1.5, 6)), table_size=int(rng.choice([1000, 1500, 2048, 3000])))
+    dist, p1, p2, kw = [
+        (Distribution.uniform(-2.0, 5.0), -2.0, 5.0, {}),
+        (Distribution.normal(1.0, 0.5), 1.0, 0.5, {}),
+        (Distribution.exponential(3.0), 3.0, 0.0, {}),
+        (beta, 0.0, 0.0, dict(cdf_table=beta._cdf_table, x_table=beta._x_table)),
+    ][kind]
+    mc = MonteCarloIntegrator(target_threads=target)
+    mc._engine.set_target_threads(int(rng.choice([64, 4096, 100_000, 1 << 20, 1 << 22])))
+    res = mc.integrate(F, dist, n_samples=n, seed=seed)
+    cfg = oracle.dispatch_config(n, target)
+    assert res.meta["n_eff"] == cfg["total_threads"] * cfg["loops_per_thread"]
+    xs = oracle.samples(kind, p1, p2, n_samples=n, seed=seed, target_threads=target, guard=1, **kw)
+    want = _expected(xs) / xs.size
+    assert np.allclose(res.values, want, rtol=3e-5, atol=3e-5), (case, target, n, kind, res.values, want)
+    # the same call as shards of a random world size
+    world = int(rng.choice([2, 3, 5, 8]))
+    cdf = mc._cdf_table(dist)
+    mod = mc._engine.module(functions_to_hip(F), rt.make_desc(rt.KIND_INTEGRATE, 3, kind))
+    parts = [mc._engine.integrate(mod, n, seed, p1, p2, target, cdf=cdf, rank=r, world=world)[0] for r in range(world)]
+    assert np.allclose(np.sum(parts, axis=0) / xs.size, want, rtol=3e-5, atol=3e-5), (case, world)
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_random_geometry_mcmc(case):
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo.api import MonteCarloIntegrator
+
+    rng = np.random.default_rng(5000 + case)
+    n_chains = int(rng.choice([1, 100, 256, 257, 1000, 3000]))
+    n_steps = int(rng.choice([1, 2, 7, 100, 513]))
+    n_burnin = int(rng.choice([0, 1, 2, 50]))
+    seed = int(rng.integers(0, 2**32))
+    kind = int(rng.integers(0, 4))
+    target = Distribution.normal(0.5, 1.0)
+    lap = Distribution.from_pdf(lambda x: math.exp(-abs(x)) / 2, support=(-12, 12), table_size=1200)
+    proposal, p1, p2 = [(Distribution.uniform(-6.0, 7.0), -6.0, 7.0), (Distribution.normal(0.0, 2.0), 0.0, 2.0),
+                        (Distribution.exponential(0.7), 0.7, 0.0), (lap, 0.0, 0.0)][kind]
+    mc = MonteCarloIntegrator()
+    res = mc.integrate_mcmc(F[:2], target, proposal, n_steps=n_steps, n_chains=n_chains, n_burnin=n_burnin, seed=seed)
+    tx, tl = target.get_log_pdf_table()
+    px, pl = proposal.get_log_pdf_table()
+    ref = oracle.mcmc([(oracle.FN_IDENTITY, 0), (oracle.FN_SQ, 0)], kind, p1, p2, tx, tl, px, pl, n_steps=n_steps,
+                      n_chains=n_chains, n_burnin=n_burnin, seed=seed, guard=1,
+                      cdf_table=proposal._cdf_table, x_table=proposal._x_table if proposal._cdf_table is not None else None)
+    assert res.meta["n_eff"] == ref["n_eff"]
+    assert np.allclose(res.values, ref["sums"][:2] / ref["n_eff"], rtol=5e-4, atol=5e-4), (case, res.values, ref["sums"][:2] / ref["n_eff"])
+    total_steps = (ref["n_eff"] // n_steps) * (n_steps + n_burnin)
+    assert abs(res.meta["accept_rate"] - ref["sums"][2] / total_steps) < 2e-3
