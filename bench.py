@@ -16,6 +16,8 @@ import sys
 import time
 from pathlib import Path
 
+import numpy as np
+
 ROOT = Path(__file__).resolve().parent
 for _p in (ROOT / "wgpu-monte-carlo_amd", ROOT):
     if str(_p) not in sys.path:
@@ -52,19 +54,25 @@ def prewarm_cache():
         rt.precompile(src, rt.make_desc(rt.KIND_INTEGRATE, K, dist))
 
 
-def cpu_baseline(n_samples: int):
-    """Time the CPU oracle (plain-C restatement of the reference kernel, OpenMP over the logical
-    thread index) on a bounded sample of the same workload."""
+def cpu_baseline(target_seconds: float):
+    """Time the CPU oracle (plain-C restatement of the reference kernel, OpenMP over the logical thread index,
+    all host cores) on a bounded slice of the same workload: a pilot run sizes the slice to ~target_seconds."""
     import oracle
 
     fns = [(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2), (oracle.FN_POW, 3), (oracle.FN_POW, 4)]
-    oracle.integrate(fns, oracle.NORMAL, 0.0, 1.0, n_samples=1_000_000, seed=1)     # warm up threads
+    oracle.integrate(fns, oracle.NORMAL, 0.0, 1.0, n_samples=1_000_000, seed=1)     # warm up the thread pool
+    t0 = time.perf_counter()
+    pilot = oracle.integrate(fns, oracle.NORMAL, 0.0, 1.0, n_samples=50_000_000, seed=7)
+    rate = pilot["n_eff"] / (time.perf_counter() - t0)
+    n_samples = int(min(max(rate * target_seconds, 1e8), 1e10))
     t0 = time.perf_counter()
     res = oracle.integrate(fns, oracle.NORMAL, 0.0, 1.0, n_samples=n_samples, seed=42)
     dt = time.perf_counter() - t0
     return dict(value=res["n_eff"] / dt, unit="samples/s", cores=oracle.num_threads(), kind="port",
-                sample=f"K=4 moments on N(0,1), n={n_samples:.0e} (N_eff {res['n_eff']}) of the 1e9-per-GPU workload, "
-                       f"oracle/mcx_oracle.c with OpenMP, {dt:.2f} s")
+                sample=f"K=4 moments on N(0,1), n={n_samples:.2e} (N_eff {res['n_eff']}) of the 1e9-per-GPU-per-step workload, "
+                       f"oracle/mcx_oracle.c (C restatement of the reference kernel, f32, same counter stream) with OpenMP on "
+                       f"{oracle.num_threads()} threads, {dt:.1f} s wall",
+                mean_error_vs_truth=[float(v) for v in (res["sums"] / res["n_eff"] - np.array(TRUTH))])
 
 
 def main():
@@ -73,7 +81,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--samples-per-gpu", type=float, default=1e9)
-    ap.add_argument("--cpu-samples", type=float, default=2e8)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the CPU baseline slice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--target-phys", type=int, default=0, help="physical threads per launch (tuning)")
     ap.add_argument("--rng", default="pcg_ref", help="pcg_ref (the reference's stream; the headline) or philox")
@@ -231,7 +239,7 @@ def main():
                                      "HBM is ~4e-5 of peak by design, not the bound"},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(int(args.cpu_samples))
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
