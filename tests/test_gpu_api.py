@@ -208,3 +208,21 @@ def test_std_error_output():
     r = mc.integrate_importance_sampling([lambda x: x > 3.0], D().normal(0.0, 1.0), D().normal(3.5, 1.0), n_samples=5_000_000)
     assert abs(r.values[0] - 0.0013499) < 4 * r.meta["std_error"][0] and r.meta["std_error"][0] < 3e-6
     assert "std_error" not in plain.integrate(fns, D().normal(0.0, 1.0), n_samples=100_000).meta
+
+
+def test_convenience_calls_reuse_the_device_engine():
+    """integrate() builds a new MonteCarloIntegrator per call (as in the reference); engines, loaded modules and
+    resident tables are shared per device, so the second call costs no device initialisation or module load."""
+    import time
+
+    from wgpu_montecarlo import MonteCarloIntegrator, integrate
+
+    f = lambda x: x * x
+    integrate([f], D().normal(0.0, 1.0), n_samples=100_000)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        r = integrate([f], D().normal(0.0, 1.0), n_samples=100_000)
+    per_call_ms = (time.perf_counter() - t0) / 20 * 1e3
+    assert abs(r.values[0] - 1.0) < 0.02
+    assert MonteCarloIntegrator()._engine is MonteCarloIntegrator()._engine
+    assert per_call_ms < 5.0, per_call_ms

@@ -155,27 +155,19 @@ class MonteCarloIntegrator:
         self._std_error = bool(std_error)
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0")) if runtime.device_count() > 1 else 0
-        self._engine = runtime.Engine(device)       # RuntimeError("Failed to initialize GPU: ...") without a GPU
+        # RuntimeError("Failed to initialize GPU: ...") without a GPU. Engines are shared per device: building an
+        # integrator per call (as the convenience functions do) costs no device initialisation after the first.
+        self._engine = runtime.Engine.shared(device)
         self._integrator = self._engine             # attribute name the reference uses for its native object
         self._target_threads = target_threads
         self._math = math
         self._precise_sampler = math == "precise"
         self._guard = not strict_reference_uniform
         self._group = distributed.Group(process_group) if process_group is not None else distributed.default_group()
-        self._tables = {}
 
     # ---- helpers ---------------------------------------------------------------------------------
     def _table(self, kind: int, keys: np.ndarray, values: np.ndarray) -> runtime.Table:
-        keys = np.ascontiguousarray(keys, dtype=np.float32)
-        values = np.ascontiguousarray(values, dtype=np.float32)
-        key = (kind, keys.tobytes(), values.tobytes())
-        tb = self._tables.get(key)
-        if tb is None:
-            if len(self._tables) > 64:
-                self._tables.clear()
-            tb = self._engine.table(kind, keys, values)
-            self._tables[key] = tb
-        return tb
+        return self._engine.cached_table(kind, keys, values)
 
     def _cdf_table(self, dist: Distribution) -> Optional[runtime.Table]:
         if dist.dist_type != DistributionType.CUSTOM:

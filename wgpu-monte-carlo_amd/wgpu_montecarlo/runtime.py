@@ -291,11 +291,38 @@ class Module:
 class Engine:
     """One GPU + one stream (replaces the reference's ComputeEngine, src/engine.rs:70-131)."""
 
+    _shared = {}
+    _shared_lock = threading.Lock()
+
     def __init__(self, device: int = 0):
         self._h = C.c_void_p()
         check(load().mcx_engine_create(int(device), C.byref(self._h)))
         self.device = int(device)
         self._modules = {}
+        self._tables = {}
+
+    @classmethod
+    def shared(cls, device: int = 0) -> "Engine":
+        """The process-wide engine of a device: integrators (and the convenience functions, which build a new
+        integrator per call like the reference's) share its stream, loaded modules and resident tables."""
+        with cls._shared_lock:
+            eng = cls._shared.get(int(device))
+            if eng is None or not eng._h:
+                eng = cls(device)
+                cls._shared[int(device)] = eng
+            return eng
+
+    def cached_table(self, kind: int, keys, values) -> "Table":
+        keys = np.ascontiguousarray(keys, dtype=np.float32)
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        key = (kind, keys.tobytes(), values.tobytes())
+        tb = self._tables.get(key)
+        if tb is None:
+            if len(self._tables) > 64:
+                self._tables.clear()
+            tb = Table(self, kind, keys, values)
+            self._tables[key] = tb
+        return tb
 
     def module(self, user_src: str, desc: ModuleDesc) -> Module:
         key = (user_src, bytes(desc))
@@ -365,6 +392,9 @@ class Engine:
         for mod in list(self._modules.values()):
             mod.release()
         self._modules.clear()
+        for tb in list(self._tables.values()):
+            tb.release()
+        self._tables.clear()
         if self._h:
             load().mcx_engine_destroy(self._h)
             self._h = C.c_void_p()
