@@ -125,8 +125,9 @@ typedef struct mcx_module_desc {
     int32_t block;             /* threads per workgroup: 0 = auto (256, or 1024 when tables are staged) */
     int32_t tables_lds;        /* 1 (default): tables staged in LDS; 0: read from HBM/L2 */
     int32_t rng;               /* 0 (default): the reference's PCG counter hash (parity stream);
-                                * 1: Philox4x32-10, counter (idx, i/4, 0, 0), key (seed, 'MCX1') -- opt-in for runs that
-                                * draw more than ~2^32 uniforms (K1/K2 only) */
+                                * 1: Philox4x32-10, key (seed, 'MCX1'); counter (idx, i/4, 0, 0) for K1/K2 (four iterations per
+                                * call), (idx, it, 1, 0) for K3 (one call per MH step) -- opt-in for runs that draw more
+                                * than ~2^32 uniforms */
     int32_t second_moments;    /* 1: rows k..2k-1 of the result hold the sums of (f_i * w)^2 (standard errors); the
                                 * result then has 2k rows (integrate / importance sampling only) */
 } mcx_module_desc;

@@ -50,7 +50,7 @@ class _McmcArgs(C.Structure):
                 ("param1", C.c_float), ("param2", C.c_float), ("table_size", C.c_uint32),
                 ("cdf_table", C.POINTER(C.c_float)), ("x_table", C.POINTER(C.c_float)),
                 ("target_logpdf", C.POINTER(C.c_float)), ("proposal_logpdf", C.POINTER(C.c_float)),
-                ("guard", C.c_int32)]
+                ("guard", C.c_int32), ("rng", C.c_int32)]
 
 
 _lib = None
@@ -221,7 +221,7 @@ def samples(dist_type, param1=0.0, param2=1.0, n_samples=1_000_000, seed=42, cdf
 
 def mcmc(fns, proposal_type, param1, param2, target_x, target_logpdf, proposal_x, proposal_logpdf,
          n_steps=1000, n_chains=256, n_burnin=100, seed=42, cdf_table=None, x_table=None,
-         target_threads=None, guard=0, trace_chains=0):
+         target_threads=None, guard=0, trace_chains=0, rng=0):
     """Restated K3. Returns dict(ref, sums (K+1, last = accepted steps), n_eff, trace)."""
     a = _McmcArgs()
     a.n_steps, a.n_chains, a.n_burnin = int(n_steps), int(n_chains), int(n_burnin)
@@ -236,6 +236,7 @@ def mcmc(fns, proposal_type, param1, param2, target_x, target_logpdf, proposal_x
     pl = interleave(proposal_x, proposal_logpdf)
     a.target_logpdf, a.proposal_logpdf = _fp(tl), _fp(pl)
     a.guard = int(guard)
+    a.rng = int(rng)
     K = len(fns)
     ref = np.zeros(K, dtype=np.float32)
     sums = np.zeros(K + 1, dtype=np.float64)

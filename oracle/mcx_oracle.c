@@ -358,7 +358,30 @@ typedef struct {
     const float* target_logpdf;    /* interleaved [n, x0, lp0, ...] */
     const float* proposal_logpdf;  /* interleaved */
     int32_t  guard;
+    int32_t  rng;                  /* 0: reference stream; 1: libmcx's opt-in Philox stream (one call per step) */
 } orc_mcmc_args;
+
+/* Philox stream of libmcx for K3: call (idx, it, 1, 0), key (seed, 'MCX1'); outputs (0,1) -> proposal (z0 of the
+ * Box-Muller pair, or one uniform from output 0), output 2 -> accept uniform. it = 0 is the initial state. */
+static float mcmc_sample_q_philox(const orc_mcmc_args* a, uint32_t idx, uint32_t it, uint32_t* accept_hash) {
+    uint32_t ctr[4] = {idx, it, 1u, 0u}, key[2] = {a->seed, 0x4d435831u}, o[4];
+    orc_philox4x32_10(ctr, key, o);
+    if (accept_hash) *accept_hash = o[2];
+    if (a->proposal_type == ORC_DIST_NORMAL) {
+        float u1 = u_from_hash(o[0]);
+        if (a->guard && o[0] == 0u) u1 = 0x1.0p-33f;
+        float r = sqrtf(-2.0f * logf(u1));
+        float theta = 6.283185307179586f * u_from_hash(o[1]);
+        return a->param1 + a->param2 * (r * cosf(theta));
+    }
+    float rng = u_from_hash(o[0]);
+    if (a->proposal_type == ORC_DIST_UNIFORM) {
+        if (a->guard && rng >= 1.0f) rng = 0x1.fffffep-1f;
+        return orc_sample_uniform(rng, a->param1, a->param2);
+    }
+    if (a->proposal_type == ORC_DIST_EXPONENTIAL) return orc_sample_exponential(rng, a->param1);
+    return orc_sample_from_cdf_table(rng, a->table_size, a->cdf_table, a->x_table);
+}
 
 static float mcmc_sample_q(const orc_mcmc_args* a, orc_bm_state* bm, uint32_t idx, uint32_t iter) {
     if (a->proposal_type == ORC_DIST_NORMAL)
@@ -388,7 +411,8 @@ int orc_mcmc(const orc_mcmc_args* a, const orc_fn* fns, int K, float* out_ref, d
     for (int64_t t = 0; t < (int64_t)T; ++t) {
         uint32_t idx = (uint32_t)t;
         orc_bm_state bm = {0, 0.0f};
-        float current_x = mcmc_sample_q(a, &bm, idx, 0u);                       /* shader_gen.rs:445-463 */
+        float current_x = a->rng == 1 ? mcmc_sample_q_philox(a, idx, 0u, NULL)
+                                      : mcmc_sample_q(a, &bm, idx, 0u);         /* shader_gen.rs:445-463 */
         float current_log_p = orc_table_lookup(a->target_logpdf, current_x, -100.0f);
         uint64_t accepted = 0;
         float acc[64];
@@ -396,12 +420,15 @@ int orc_mcmc(const orc_mcmc_args* a, const orc_fn* fns, int K, float* out_ref, d
         for (int k = 0; k < K; ++k) { acc[k] = 0.0f; acc64[k] = 0.0; }
         uint32_t total = a->n_burnin + a->n_steps;
         for (uint32_t it = 1u; it <= total; ++it) {                              /* burn-in: i+1 ; sampling: i+n_burnin+1 */
-            float proposal_x = mcmc_sample_q(a, &bm, idx, it + 1000000u);       /* shader_gen.rs:477-489 */
+            uint32_t accept_hash = 0u;
+            float proposal_x = a->rng == 1 ? mcmc_sample_q_philox(a, idx, it, &accept_hash)
+                                           : mcmc_sample_q(a, &bm, idx, it + 1000000u);   /* shader_gen.rs:477-489 */
             float proposal_log_p_target = orc_table_lookup(a->target_logpdf, proposal_x, -100.0f);
             float proposal_log_q = orc_table_lookup(a->proposal_logpdf, proposal_x, -100.0f);
             float current_log_q = orc_table_lookup(a->proposal_logpdf, current_x, -100.0f);
             float log_alpha = proposal_log_p_target + current_log_q - current_log_p - proposal_log_q;
-            float u = orc_random_uniform(a->seed + 999999u, idx, it);            /* shader_gen.rs:529 */
+            float u = a->rng == 1 ? u_from_hash(accept_hash)
+                                  : orc_random_uniform(a->seed + 999999u, idx, it);    /* shader_gen.rs:529 */
             if (logf(u) < log_alpha) {
                 current_x = proposal_x;
                 current_log_p = proposal_log_p_target;

@@ -369,3 +369,24 @@ def test_large_tables_and_capped_search(integrator, n_prop, n_tgt, in_lds):
                            cdf_table=proposal._cdf_table, x_table=proposal._x_table)
     ok, msg = close(plain.values, ref["sums"] / ref["n_eff"], tol=2e-6)
     assert ok, msg
+
+
+@pytest.mark.parametrize("kind", ["normal", "uniform", "custom"])
+def test_philox_mcmc_matches_its_oracle(kind):
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+
+    mc = MonteCarloIntegrator(rng="philox")
+    target = Distribution.normal(0.3, 1.0)
+    if kind == "normal":
+        proposal, code, p1, p2 = Distribution.normal(0.0, 2.0), oracle.NORMAL, 0.0, 2.0
+    elif kind == "uniform":
+        proposal, code, p1, p2 = Distribution.uniform(-6.0, 7.0), oracle.UNIFORM, -6.0, 7.0
+    else:
+        proposal = Distribution.from_pdf(lambda x: math.exp(-abs(x)) / 2, support=(-12, 12))
+        code, p1, p2 = oracle.CUSTOM, 0.0, 0.0
+    res = mc.integrate_mcmc([lambda x: x, lambda x: x**2], target, proposal, n_steps=1200, n_chains=700, n_burnin=33, seed=21)
+    ref = _mcmc_oracle(target, proposal, code, p1, p2, n_steps=1200, n_chains=700, n_burnin=33, seed=21, rng=1)
+    assert res.meta["n_eff"] == ref["n_eff"] == 768 * 1200
+    ok, msg = close(res.values, ref["sums"][:2] / ref["n_eff"], tol=2e-4)
+    assert ok, msg
+    assert abs(res.values[0] - 0.3) < 0.02 and abs(res.values[1] - 1.09) < 0.03

@@ -374,7 +374,20 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 
     // ---- initial state ~ proposal, counter iter = 0 (shader_gen.rs:445-463) ----
     float cur_x;
+#if MCX_RNG == 1
+    // Philox stream (opt-in): one call per step, counter (idx, it, 1, 0): outputs (x, y) feed the proposal
+    // (a Box-Muller pair of which z0 is used, or one uniform), output z is the accept uniform. it = 0: initial state.
+    {
+        const McxU4 o = mcx_philox4x32_10(McxU4{idx, 0u, 1u, 0u}, a.seed, MCX_PHILOX_KEY1);
 #if MCX_DIST == MCX_DIST_NORMAL
+        float z0, z1;
+        mcx_box_muller(o.x, o.y, z0, z1);
+        cur_x = a.param1 + a.param2 * z0;
+#else
+        cur_x = mcx_draw_proposal(o.x, a, cdf_tb);
+#endif
+    }
+#elif MCX_DIST == MCX_DIST_NORMAL
     float z_cached;
     {
         u32 s0 = mcx_state(a.seed, idx, 0u);
@@ -390,15 +403,16 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #endif
     float cur_lp = mcx_table_lookup(lp_tb, cur_x, -100.0f);
     float cur_lq = mcx_table_lookup(lq_tb, cur_x, -100.0f);   // pure function of cur_x: cached
+#if MCX_RNG == 0
     u32 st_acc = mcx_state(a.seed + MCX_ACCEPT_SEED_OFFSET, idx, 1u);
+#endif
 
-    // One Metropolis-Hastings step with proposal prop_x (shader_gen.rs:511-537); `it` is wave-uniform.
-    auto mh_step = [&](u32 it, float prop_x) {
+    // One Metropolis-Hastings step with proposal prop_x and accept hash ha (shader_gen.rs:511-537);
+    // `it` is wave-uniform.
+    auto mh_step_h = [&](u32 it, float prop_x, u32 ha) {
         float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
         float prop_lq = mcx_table_lookup(lq_tb, prop_x, -100.0f);
         float log_alpha = prop_lp + cur_lq - cur_lp - prop_lq;                     // shader_gen.rs:526
-        u32 ha = mcx_pcg_out(st_acc);                                              // U(seed+999999, idx, it)
-        st_acc += MCX_STATE_STEP;
 #if MCX_PRECISE_SAMPLER
         float ln_u = logf(mcx_u01_closed(ha));
 #else
@@ -418,8 +432,27 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
             }
         }
     };
+#if MCX_RNG == 0
+    // reference stream: the accept uniform is U(seed + 999999, idx, it) (shader_gen.rs:529)
+    auto mh_step = [&](u32 it, float prop_x) {
+        const u32 ha = mcx_pcg_out(st_acc);
+        st_acc += MCX_STATE_STEP;
+        mh_step_h(it, prop_x, ha);
+    };
+#endif
 
+#if MCX_RNG == 1
+    for (u32 it = 1u; it <= total_steps; ++it) {
+        const McxU4 o = mcx_philox4x32_10(McxU4{idx, it, 1u, 0u}, a.seed, MCX_PHILOX_KEY1);
 #if MCX_DIST == MCX_DIST_NORMAL
+        float z0, z1;
+        mcx_box_muller(o.x, o.y, z0, z1);
+        mh_step_h(it, a.param1 + a.param2 * z0, o.z);
+#else
+        mh_step_h(it, mcx_draw_proposal(o.x, a, cdf_tb), o.z);
+#endif
+    }
+#elif MCX_DIST == MCX_DIST_NORMAL
     // odd `it` consumes the z1 cached by the previous draw (it = 1: the initial draw's), even `it` draws a
     // new pair from counters 2*(it+OFFSET), +1 (distribution.rs:90-114 through shader_gen.rs:481)
     u32 it = 1u;

@@ -138,7 +138,7 @@ class MonteCarloIntegrator:
             (reference behaviour, can produce log(0)); default False guards the end points.
         rng: "pcg_ref" (default) is the reference's counter hash -- bit-exact sample indexing, but a 32-bit
             counter space that is oversubscribed beyond ~4e9 uniforms per call; "philox" is Philox4x32-10 with a
-            128-bit counter (integrate / importance sampling; MCMC keeps the reference stream).
+            128-bit counter (four iterations per call for integrate / importance sampling, one call per MH step).
         std_error: also accumulate sum (f_k w)^2 in the same pass; integrate / importance-sampling results then
             carry result.meta["std_error"][k] = sqrt((E[(f w)^2] - E[f w]^2) / N_eff) (extension; K <= 32).
     """
@@ -302,7 +302,7 @@ class MonteCarloIntegrator:
         cdf = self._cdf_table(proposal_distribution)
         lds_ok = self._lds_bytes(cdf, t_table, q_table) <= _LDS_TABLE_BUDGET
         desc = runtime.make_desc(runtime.KIND_MCMC, len(functions), code, guard_endpoints=self._guard,
-                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok)
+                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng)
         mod = self._engine.module(user_src, desc)
         rank, world = self._rank_world()
         k = len(functions)
