@@ -84,3 +84,33 @@ def test_random_geometry_mcmc(case):
     assert np.allclose(res.values, ref["sums"][:2] / ref["n_eff"], rtol=5e-4, atol=5e-4), (case, res.values, ref["sums"][:2] / ref["n_eff"])
     total_steps = (ref["n_eff"] // n_steps) * (n_steps + n_burnin)
     assert abs(res.meta["accept_rate"] - ref["sums"][2] / total_steps) < 2e-3
+
+
+def test_many_fused_functions(integrator):
+    """K = 64 (the maximum) on U(0,1): E[x^k] = 1/(k+1); K = 33 with importance sampling; K = 20 in the MH kernel."""
+    from wgpu_montecarlo import Distribution
+
+    fns = [lambda x, k=k: x**k for k in range(1, 65)]
+    r = integrator.integrate(fns, Distribution.uniform(0.0, 1.0), n_samples=20_000_000, seed=3)
+    truth = 1.0 / (np.arange(1, 65) + 1.0)
+    sigma = np.sqrt((1.0 / (2 * np.arange(1, 65) + 1.0) - truth**2) / r.meta["n_eff"])
+    assert np.all(np.abs(r.values - truth) < 4 * sigma), np.abs(r.values - truth) / sigma
+    xs = oracle.samples(oracle.UNIFORM, 0.0, 1.0, n_samples=65536 * 4, seed=8, guard=1).astype(np.float64)
+    small = integrator.integrate(fns, Distribution.uniform(0.0, 1.0), n_samples=65536 * 4, seed=8)
+    want = np.array([(xs**k).mean() for k in range(1, 65)])
+    assert np.allclose(small.values, want, rtol=2e-5, atol=1e-7)
+    with pytest.raises(ValueError, match="at most 64"):
+        integrator.integrate(fns + [lambda x: x], Distribution.uniform(0.0, 1.0), n_samples=1000)
+    r = integrator.integrate_importance_sampling(fns[:33], Distribution.uniform(0.0, 1.0), Distribution.uniform(-0.5, 1.5),
+                                                 n_samples=5_000_000, seed=5)
+    assert np.all(np.abs(r.values - truth[:33]) < 0.01)
+    r = integrator.integrate_mcmc(fns[:20], Distribution.beta(2.0, 5.0), Distribution.uniform(0.0, 1.0), n_steps=4000,
+                                  n_chains=2048, n_burnin=200, seed=7)
+
+    def beta_moment(k):
+        m = 1.0
+        for j in range(k):
+            m *= (2 + j) / (7 + j)
+        return m
+
+    assert np.all(np.abs(r.values - [beta_moment(k) for k in range(1, 21)]) < 0.01)

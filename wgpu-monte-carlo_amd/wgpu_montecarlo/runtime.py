@@ -7,6 +7,7 @@ raises RuntimeError("Failed to initialize GPU: ...") exactly where the reference
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 import threading
@@ -312,6 +313,18 @@ class Engine:
                 cls._shared[int(device)] = eng
             return eng
 
+    @classmethod
+    def close_shared(cls) -> None:
+        """Release the shared engines (registered with atexit: device objects are freed while the HIP runtime is
+        still fully alive, not in whatever order module teardown destroys Python objects)."""
+        with cls._shared_lock:
+            engines, cls._shared = list(cls._shared.values()), {}
+        for eng in engines:
+            try:
+                eng.close()
+            except Exception:
+                pass
+
     def cached_table(self, kind: int, keys, values) -> "Table":
         keys = np.ascontiguousarray(keys, dtype=np.float32)
         values = np.ascontiguousarray(values, dtype=np.float32)
@@ -404,3 +417,6 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+
+atexit.register(Engine.close_shared)
