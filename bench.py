@@ -29,9 +29,9 @@ TRUTH = (0.0, 1.0, 0.0, 3.0)
 SIGMA = (1.0, 2.0 ** 0.5, 15.0 ** 0.5, 96.0 ** 0.5)
 
 # Algorithmic VALU cost of one sample of this workload, in lane-op equivalents (DESIGN.md "Roofline"):
-# per Box-Muller pair 25 plain ops + 2 integer multiplies (x4) + 4 transcendentals (x2), per sample
-# 3 multiplies + 4 adds  ->  (25 + 8 + 8) / 2 + 7 = 27.5
-OPS_PER_SAMPLE = 27.5
+# per Box-Muller pair 23 plain ops (N(0,1): no affine map) + 2 integer multiplies (x4) + 4 transcendentals (x2),
+# per sample 3 multiplies + 4 adds  ->  (23 + 8 + 8) / 2 + 7 = 26.5   (27.5 for a general N(mean, std))
+OPS_PER_SAMPLE = 26.5
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9      # 7.86e13: CUs x SIMDs x lanes x clock (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0
 
@@ -52,6 +52,8 @@ def prewarm_cache():
     src = functions_to_hip(moment_functions())
     for dist in (rt.DIST_UNIFORM, rt.DIST_NORMAL, rt.DIST_EXPONENTIAL, rt.DIST_CUSTOM):
         rt.precompile(src, rt.make_desc(rt.KIND_INTEGRATE, K, dist))
+    rt.precompile(src, rt.make_desc(rt.KIND_INTEGRATE, K, rt.DIST_NORMAL, unit_params=True))      # N(0,1): the headline
+    rt.precompile(src, rt.make_desc(rt.KIND_INTEGRATE, K, rt.DIST_NORMAL, unit_params=True, rng=rt.RNG_PHILOX))
 
 
 def cpu_baseline(target_seconds: float):

@@ -128,6 +128,8 @@ typedef struct mcx_module_desc {
                                 * 1: Philox4x32-10, key (seed, 'MCX1'); counter (idx, i/4, 0, 0) for K1/K2 (four iterations per
                                 * call), (idx, it, 1, 0) for K3 (one call per MH step) -- opt-in for runs that draw more
                                 * than ~2^32 uniforms */
+    int32_t unit_params;       /* 1: the caller guarantees param1/param2 are the identity -- normal(0,1), uniform(0,1),
+                                * exponential(1) -- so the affine map of the sampler is not emitted (bit-identical results) */
     int32_t second_moments;    /* 1: rows k..2k-1 of the result hold the sums of (f_i * w)^2 (standard errors); the
                                 * result then has 2k rows (integrate / importance sampling only) */
 } mcx_module_desc;

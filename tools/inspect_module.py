@@ -34,7 +34,7 @@ def k32():
 
 def build(which, fast):
     if which == "c2":
-        return functions_to_hip([f1, f2, f3, f4], fast), rt.make_desc(rt.KIND_INTEGRATE, 4, rt.DIST_NORMAL)
+        return functions_to_hip([f1, f2, f3, f4], fast), rt.make_desc(rt.KIND_INTEGRATE, 4, rt.DIST_NORMAL, unit_params=True)
     if which == "c3":
         src = functions_to_hip([f1, f2, f3, f4], fast) + "\n" + _pdf_to_hip(Distribution.normal(2.0, 3.0), "mcx_pdf_q", fast)
         return src, rt.make_desc(rt.KIND_INTEGRATE, 4, rt.DIST_NORMAL, weight=True, p_table=True)

@@ -51,6 +51,18 @@
 
 #define MCX_WAVES (MCX_BLOCK / 64)
 
+// Unit parameters -- normal(0,1), uniform(0,1), exponential(1) -- are specialised at JIT time: the affine map
+// mean + sigma * z (resp. min + u * (max - min), -ln(u) / lambda) is the identity and is not emitted. Bit-identical
+// results (0 + 1 * z == z); for the headline N(0,1) workload it removes 2 FMAs and a re-materialised move per pair.
+#ifndef MCX_UNIT_PARAMS
+#define MCX_UNIT_PARAMS 0
+#endif
+#if MCX_UNIT_PARAMS
+#define MCX_AFFINE(z) (z)
+#else
+#define MCX_AFFINE(z) (a.param1 + a.param2 * (z))
+#endif
+
 // Large K: per-thread f64 sums would need 2K VGPRs (K = 32 spills). Instead every MCX_FLUSH units each
 // wave reduces its f32 accumulators with xor-shuffles and lane 0 adds the K wave totals into f64 slots in
 // LDS ("LDS-staged" reduction); the registers hold f32 accumulators only.
@@ -145,10 +157,10 @@ MCX_DEV void mcx_accumulate(float x, const McxIsTables& tb, float (&acc)[MCX_K])
 MCX_DEV float mcx_draw(u32 h, const McxIntegrateArgs& a, const McxTable& cdf_tb) {
 #if MCX_DIST == MCX_DIST_UNIFORM
     (void)cdf_tb;
-    return mcx_sample_uniform(mcx_u01(h), a.param1, a.param2);
+    return MCX_UNIT_PARAMS ? mcx_u01(h) : mcx_sample_uniform(mcx_u01(h), a.param1, a.param2);
 #elif MCX_DIST == MCX_DIST_EXPONENTIAL
     (void)cdf_tb;
-    return mcx_sample_exponential(mcx_u01_closed(h), a.param1);
+    return mcx_sample_exponential(mcx_u01_closed(h), MCX_UNIT_PARAMS ? 1.0f : a.param1);
 #else
     return mcx_sample_cdf(cdf_tb, mcx_u01_closed(h));
 #endif
@@ -222,8 +234,8 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 #if MCX_DIST == MCX_DIST_NORMAL
         float z0, z1;
         mcx_box_muller(h_first, h_second, z0, z1);
-        mcx_accumulate(a.param1 + a.param2 * z0, is_tb, accA);
-        if (n_valid > 1u) mcx_accumulate(a.param1 + a.param2 * z1, is_tb, MCX_ACC_B);
+        mcx_accumulate(MCX_AFFINE(z0), is_tb, accA);
+        if (n_valid > 1u) mcx_accumulate(MCX_AFFINE(z1), is_tb, MCX_ACC_B);
 #else
         mcx_accumulate(mcx_draw(h_first, a, cdf_tb), is_tb, accA);
         if (n_valid > 1u) mcx_accumulate(mcx_draw(h_second, a, cdf_tb), is_tb, MCX_ACC_B);
@@ -267,8 +279,8 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
             st += 4u * MCX_STATE_STEP;
             float z0, z1;
             mcx_box_muller(h1, h2, z0, z1);
-            mcx_accumulate(a.param1 + a.param2 * z0, is_tb, accA);
-            mcx_accumulate(a.param1 + a.param2 * z1, is_tb, MCX_ACC_B);
+            mcx_accumulate(MCX_AFFINE(z0), is_tb, accA);
+            mcx_accumulate(MCX_AFFINE(z1), is_tb, MCX_ACC_B);
         }
         MCX_FLUSH_ACC();
     }
@@ -280,7 +292,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         float z0, z1;
         mcx_box_muller(h1, h2, z0, z1);
         MCX_ZERO_ACC();
-        mcx_accumulate(a.param1 + a.param2 * z0, is_tb, accA);
+        mcx_accumulate(MCX_AFFINE(z0), is_tb, accA);
         MCX_FLUSH_ACC();
     }
 #else
@@ -339,10 +351,10 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 MCX_DEV float mcx_draw_proposal(u32 h, const McxMcmcArgs& a, const McxTable& cdf_tb) {
 #if MCX_DIST == MCX_DIST_UNIFORM
     (void)cdf_tb;
-    return mcx_sample_uniform(mcx_u01(h), a.param1, a.param2);
+    return MCX_UNIT_PARAMS ? mcx_u01(h) : mcx_sample_uniform(mcx_u01(h), a.param1, a.param2);
 #elif MCX_DIST == MCX_DIST_EXPONENTIAL
     (void)cdf_tb;
-    return mcx_sample_exponential(mcx_u01_closed(h), a.param1);
+    return mcx_sample_exponential(mcx_u01_closed(h), MCX_UNIT_PARAMS ? 1.0f : a.param1);
 #else
     return mcx_sample_cdf(cdf_tb, mcx_u01_closed(h));
 #endif
@@ -382,7 +394,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #if MCX_DIST == MCX_DIST_NORMAL
         float z0, z1;
         mcx_box_muller(o.x, o.y, z0, z1);
-        cur_x = a.param1 + a.param2 * z0;
+        cur_x = MCX_AFFINE(z0);
 #else
         cur_x = mcx_draw_proposal(o.x, a, cdf_tb);
 #endif
@@ -393,7 +405,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
         u32 s0 = mcx_state(a.seed, idx, 0u);
         float z0;
         mcx_box_muller(mcx_pcg_out(s0), mcx_pcg_out(s0 + MCX_STATE_STEP), z0, z_cached);
-        cur_x = a.param1 + a.param2 * z0;       // z1 stays cached for step it = 1
+        cur_x = MCX_AFFINE(z0);       // z1 stays cached for step it = 1
     }
     // proposal state for even `it`: counters 2*(it+OFFSET), 2*(it+OFFSET)+1
     u32 st_prop = mcx_state(a.seed, idx, 2u * (2u + MCX_PROP_ITER_OFFSET));
@@ -447,7 +459,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #if MCX_DIST == MCX_DIST_NORMAL
         float z0, z1;
         mcx_box_muller(o.x, o.y, z0, z1);
-        mh_step_h(it, a.param1 + a.param2 * z0, o.z);
+        mh_step_h(it, MCX_AFFINE(z0), o.z);
 #else
         mh_step_h(it, mcx_draw_proposal(o.x, a, cdf_tb), o.z);
 #endif
@@ -456,18 +468,18 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     // odd `it` consumes the z1 cached by the previous draw (it = 1: the initial draw's), even `it` draws a
     // new pair from counters 2*(it+OFFSET), +1 (distribution.rs:90-114 through shader_gen.rs:481)
     u32 it = 1u;
-    if (total_steps >= 1u) { mh_step(1u, a.param1 + a.param2 * z_cached); it = 2u; }
+    if (total_steps >= 1u) { mh_step(1u, MCX_AFFINE(z_cached)); it = 2u; }
     for (; it + 1u <= total_steps; it += 2u) {
         float z0, z1;
         mcx_box_muller(mcx_pcg_out(st_prop), mcx_pcg_out(st_prop + MCX_STATE_STEP), z0, z1);
         st_prop += 4u * MCX_STATE_STEP;
-        mh_step(it, a.param1 + a.param2 * z0);
-        mh_step(it + 1u, a.param1 + a.param2 * z1);
+        mh_step(it, MCX_AFFINE(z0));
+        mh_step(it + 1u, MCX_AFFINE(z1));
     }
     if (it <= total_steps && it >= 2u) {
         float z0, z1;
         mcx_box_muller(mcx_pcg_out(st_prop), mcx_pcg_out(st_prop + MCX_STATE_STEP), z0, z1);
-        mh_step(it, a.param1 + a.param2 * z0);
+        mh_step(it, MCX_AFFINE(z0));
     }
 #else
     for (u32 it = 1u; it <= total_steps; ++it) {

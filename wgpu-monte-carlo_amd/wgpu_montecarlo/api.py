@@ -123,6 +123,13 @@ def _dist_params(dist: Distribution):
     return code, 0.0, 0.0
 
 
+def _unit_params(code: int, p1: float, p2: float) -> bool:
+    """normal(0,1) / uniform(0,1) / exponential(1): the sampler's affine map is the identity and is specialised away."""
+    if code == runtime.DIST_NORMAL or code == runtime.DIST_UNIFORM:
+        return p1 == 0.0 and p2 == 1.0
+    return code == runtime.DIST_EXPONENTIAL and p1 == 1.0
+
+
 class MonteCarloIntegrator:
     """Fused multi-function Monte-Carlo integrator on one MI355X (or one rank of N).
 
@@ -230,7 +237,7 @@ class MonteCarloIntegrator:
         k = len(functions)
         desc = runtime.make_desc(runtime.KIND_INTEGRATE, k, code, guard_endpoints=self._guard,
                                  precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng,
-                                 second_moments=self._std_error)
+                                 second_moments=self._std_error, unit_params=_unit_params(code, p1, p2))
         mod = self._engine.module(user_src, desc)
         rank, world = self._rank_world()
         values, n_eff = self._run(k * (2 if self._std_error else 1), lambda d_sums, stream: self._engine.integrate(
@@ -268,7 +275,8 @@ class MonteCarloIntegrator:
         desc = runtime.make_desc(runtime.KIND_INTEGRATE, k, code, weight=True,
                                  p_table=p_table is not None, q_table=q_table is not None,
                                  guard_endpoints=self._guard, precise_sampler=self._precise_sampler,
-                                 tables_lds=lds_ok, rng=self._rng, second_moments=self._std_error)
+                                 tables_lds=lds_ok, rng=self._rng, second_moments=self._std_error,
+                                 unit_params=_unit_params(code, p1, p2))
         mod = self._engine.module(user_src, desc)
         rank, world = self._rank_world()
         values, n_eff = self._run(k * (2 if self._std_error else 1), lambda d_sums, stream: self._engine.integrate(
@@ -302,7 +310,8 @@ class MonteCarloIntegrator:
         cdf = self._cdf_table(proposal_distribution)
         lds_ok = self._lds_bytes(cdf, t_table, q_table) <= _LDS_TABLE_BUDGET
         desc = runtime.make_desc(runtime.KIND_MCMC, len(functions), code, guard_endpoints=self._guard,
-                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng)
+                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng,
+                                 unit_params=_unit_params(code, p1, p2))
         mod = self._engine.module(user_src, desc)
         rank, world = self._rank_world()
         k = len(functions)
@@ -327,7 +336,8 @@ class MonteCarloIntegrator:
         cdf = self._cdf_table(distribution)
         lds_ok = self._lds_bytes(cdf) <= _LDS_TABLE_BUDGET
         desc = runtime.make_desc(runtime.KIND_INTEGRATE, len(functions), code, guard_endpoints=self._guard,
-                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng)
+                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng,
+                                 unit_params=_unit_params(code, p1, p2))
         return PreparedIntegrand(self, self._engine.module(user_src, desc), len(functions), p1, p2, cdf)
 
     def _meta(self, n_eff: int, values=None, k: int = 0) -> dict:
