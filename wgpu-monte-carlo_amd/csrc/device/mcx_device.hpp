@@ -130,10 +130,11 @@ MCX_DEV void mcx_box_muller(u32 h1, u32 h2, float& z0, float& z1) {
     z0 = r * cosf(theta);
     z1 = r * sinf(theta);
 #else
-    // -2 ln(f1 * 2^-32) = (32 - log2 f1) * 2 ln 2, never negative
+    // -2 ln(f1 * 2^-32) = (32 - log2 f1) * 2 ln 2 >= 0. Only a 1-ulp overshoot of v_log_f32 at f1 ~ 2^32 could make it
+    // -5e-6; |.| is an input modifier of v_sqrt_f32 (no instruction) and leaves every r2 >= 0 untouched.
     float l2 = __builtin_amdgcn_logf(f1);
-    float r2 = fmaxf(fmaf(l2, -0x1.62e43p+0f, 32.0f * 0x1.62e43p+0f), 0.0f);
-    float r = __builtin_amdgcn_sqrtf(r2);
+    float r2 = fmaf(l2, -0x1.62e43p+0f, 32.0f * 0x1.62e43p+0f);
+    float r = __builtin_amdgcn_sqrtf(__builtin_fabsf(r2));
     z0 = r * __builtin_amdgcn_cosf(u2);
     z1 = r * __builtin_amdgcn_sinf(u2);
 #endif
