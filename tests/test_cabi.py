@@ -99,7 +99,7 @@ def test_module_source_and_precompile_without_gpu():
     desc = rt.make_desc(rt.KIND_INTEGRATE, 2, rt.DIST_NORMAL)
     text = rt.module_source(src, desc)
     for piece in ("#define MCX_K 2", "#define MCX_DIST 1", "mcx_integrate_kernel", "mcx_fold_kernel",
-                  "user_func_1", "mcx_pcg_out", "acc[1] += mcx_b2f(user_func_1(x)) * w;"):
+                  "user_func_1", "mcx_pcg_out", "acc[1 * S] += mcx_b2f(user_func_1(x)) * w;"):
         assert piece in text
     rt.precompile(src, desc)
     assert rt.precompile(src, desc) in (1, 2)       # second time: memory or disk cache hit

@@ -201,7 +201,9 @@ def test_std_error_output():
     plain = MonteCarloIntegrator()
     fns = [lambda x: x, lambda x: x**2, lambda x: x**3, lambda x: x**4]
     r = mc.integrate(fns, D().normal(0.0, 1.0), n_samples=10_000_000, seed=42)
-    assert np.array_equal(r.values, plain.integrate(fns, D().normal(0.0, 1.0), n_samples=10_000_000, seed=42).values)
+    # same samples, same sums up to the compiler's choice of fused multiply-adds in the two modules
+    assert np.allclose(r.values, plain.integrate(fns, D().normal(0.0, 1.0), n_samples=10_000_000, seed=42).values,
+                       rtol=0, atol=1e-7)
     want = np.sqrt(np.array([1.0, 2.0, 15.0, 96.0]) / r.meta["n_eff"])
     assert np.allclose(r.meta["std_error"], want, rtol=0.02)
     assert np.all(np.abs(r.values - [0, 1, 0, 3]) < 4 * r.meta["std_error"])

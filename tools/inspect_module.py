@@ -59,7 +59,7 @@ def main():
     hip = out / f"{args.which}.hip"
     hip.write_text("#include <hip/hip_runtime.h>\n" + text)
     asm = out / f"{args.which}.s"
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "--cuda-device-only",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-fno-slp-vectorize", "--cuda-device-only",
            "-S", str(hip), "-o", str(asm), "-Rpass-analysis=kernel-resource-usage"] + args.flags.split()
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode:

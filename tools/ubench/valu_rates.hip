@@ -40,7 +40,12 @@ __global__ void __launch_bounds__(256) rate_kernel(float* out, int iters, float 
     else if constexpr (OP == 12) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[c]) : "v"(u[(c + 1) % CHAINS])); \
     else if constexpr (OP == 13) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d[c]) : "v"(u[c]), "v"(u[(c + 1) % CHAINS]) : "vcc"); \
     else if constexpr (OP == 14) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(d[c]));                 \
-    else if constexpr (OP == 15) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[c]) : "v"(u[(c + 1) % CHAINS]));
+    else if constexpr (OP == 15) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[c]) : "v"(u[(c + 1) % CHAINS]));  \
+    else if constexpr (OP == 16) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[c]) : "v"(p[(c + 1) % CHAINS]), "v"(p[(c + 2) % CHAINS])); \
+    else if constexpr (OP == 17) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(p[c]) : "v"(p[(c + 1) % CHAINS]), "v"(p[(c + 2) % CHAINS])); \
+    else if constexpr (OP == 18) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[c]) : "v"(p[(c + 1) % CHAINS])); \
+    else if constexpr (OP == 19) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[c]) : "v"(a[(c + 1) % CHAINS]), "v"(a[(c + 2) % CHAINS])); \
+    else if constexpr (OP == 20) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p[c]) : "v"(p[(c + 1) % CHAINS]), "v"(p[(c + 2) % CHAINS]));
         REP8(STEP)
 #undef STEP
     }
@@ -92,5 +97,10 @@ int main() {
     run<5>("v_pk_fma_f32", d_out, &base);
     run<6>("v_add_f64", d_out, &base);
     run<14>("v_fma_f64", d_out, &base);
+    run<19>("v_fma_f32 3src", d_out, &base);
+    run<16>("v_pk_fma_f32 3src", d_out, &base);
+    run<20>("v_pk_fma opsel", d_out, &base);
+    run<17>("v_pk_mul_f32 2src", d_out, &base);
+    run<18>("v_pk_add_f32 2src", d_out, &base);
     return 0;
 }

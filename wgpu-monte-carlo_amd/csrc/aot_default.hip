@@ -21,10 +21,10 @@ MCX_DEV float user_func_0(float x) { return x; }
 MCX_DEV float user_func_1(float x) { return x * x; }
 MCX_DEV float user_func_2(float x) { return x * x * x; }
 MCX_DEV float user_func_3(float x) { return (x * x) * (x * x); }
-MCX_DEV void mcx_eval_all(float x, float w, float (&acc)[MCX_K]) {
-    acc[0] += mcx_b2f(user_func_0(x)) * w;
-    acc[1] += mcx_b2f(user_func_1(x)) * w;
-    acc[2] += mcx_b2f(user_func_2(x)) * w;
-    acc[3] += mcx_b2f(user_func_3(x)) * w;
+template <int S> MCX_DEV void mcx_eval_all(float x, float w, float* acc) {
+    acc[0 * S] += mcx_b2f(user_func_0(x)) * w;
+    acc[1 * S] += mcx_b2f(user_func_1(x)) * w;
+    acc[2 * S] += mcx_b2f(user_func_2(x)) * w;
+    acc[3 * S] += mcx_b2f(user_func_3(x)) * w;
 }
 #include "device/mcx_kernels.hpp"

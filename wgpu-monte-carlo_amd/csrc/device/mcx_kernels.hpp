@@ -18,8 +18,8 @@
 //     is cut into chunks so that >= 16 waves/CU are resident whatever T is; the multiset of samples
 //     is unchanged, only the summation order differs.
 //   * per-thread sums go f32 registers -> f64 registers every MCX_FLUSH units -> wave64 xor-shuffle
-//     -> LDS across waves -> one coalesced row of `partials[k][workgroup]`; a second tiny kernel
-//     folds the rows in a fixed order. No [T][K] output buffer, no host-side reduction.
+//     -> LDS across waves -> one contiguous record `partials[workgroup][k]`; a second tiny kernel
+//     folds the records in a fixed order. No [T][K] output buffer, no host-side reduction.
 //   * lookup tables are staged once per workgroup into LDS as interleaved float2.
 //   * the importance weight p/q is computed once per sample, not once per function.
 #pragma once
@@ -69,8 +69,8 @@
 #ifndef MCX_WAVE_FLUSH
 #define MCX_WAVE_FLUSH (MCX_K > 8)
 #endif
-// Two accumulator sets (one per sample of a pair) let the compiler pack the K evaluations of both samples
-// into v_pk_* without shuffles; beyond K = 16 the second set costs more registers than packing saves.
+// Two accumulator sets (one per sample of a pair) give two independent accumulation chains; beyond K = 16 the
+// second set only costs registers.
 #ifndef MCX_PAIR_LANES
 #define MCX_PAIR_LANES (MCX_K <= 16)
 #endif
@@ -135,7 +135,9 @@ MCX_DEV void mcx_block_reduce_store(double (&v)[N], double* partials) {
 // =============================================================================================
 struct McxIsTables { McxTable p, q; };
 
-MCX_DEV void mcx_accumulate(float x, const McxIsTables& tb, float (&acc)[MCX_K]) {
+// acc[k * S] is the accumulator of function k (S = 2: the A/B sample lanes are interleaved, see below).
+template <int S>
+MCX_DEV void mcx_accumulate(float x, const McxIsTables& tb, float* acc) {
 #if MCX_WEIGHT
 #if MCX_P_TABLE
     float p = mcx_table_lookup(tb.p, x, 0.0f);
@@ -147,9 +149,9 @@ MCX_DEV void mcx_accumulate(float x, const McxIsTables& tb, float (&acc)[MCX_K])
 #else
     float q = mcx_b2f(mcx_pdf_q(x));
 #endif
-    mcx_eval_all(x, mcx_div(p, q), acc);
+    mcx_eval_all<S>(x, mcx_div(p, q), acc);
 #else
-    mcx_eval_all(x, 1.0f, acc);
+    mcx_eval_all<S>(x, 1.0f, acc);
 #endif
 }
 
@@ -190,16 +192,17 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
     u1 = u1 < a.unit_end ? u1 : a.unit_end;
     if (!active) { u0 = 0u; u1 = 0u; }
 
-    // Two accumulator sets: lane A takes the first sample of every pair, lane B the second. The two
-    // evaluations of a pair are then element-wise identical instruction streams on (x0, x1) and on
-    // (accA[k], accB[k]), which the compiler packs into v_pk_mul/fma/add_f32 without register shuffles.
-    float accA[MCX_K];
+    // Two accumulator sets: lane A takes the first sample of every pair, lane B the second (two independent add chains),
+    // interleaved in one array [A0, B0, A1, B1, ...]. The modules are compiled with -fno-slp-vectorize: letting the
+    // compiler pack (A_k, B_k) into v_pk_* was measured slower on gfx950 than scalar code.
 #if MCX_PAIR_LANES
-    float accB[MCX_K];
-#define MCX_ACC_B accB
+#define MCX_ACC_S 2
 #else
-#define MCX_ACC_B accA
+#define MCX_ACC_S 1
 #endif
+    float acc[MCX_K * MCX_ACC_S];
+#define MCX_ACC_A(k) acc[(k) * MCX_ACC_S]
+#define MCX_ACC_B(k) acc[(k) * MCX_ACC_S + (MCX_ACC_S - 1)]
 
 #if MCX_WAVE_FLUSH
     __shared__ double wave_sums[MCX_WAVES][MCX_K];
@@ -208,7 +211,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 #define MCX_FLUSH_ACC()                                                                     \
     do {                                                                                    \
         _Pragma("unroll") for (int k = 0; k < MCX_K; ++k) {                                 \
-            float s_ = mcx_wave_sum_f32(MCX_PAIR_LANES ? accA[k] + MCX_ACC_B[k] : accA[k]); \
+            float s_ = mcx_wave_sum_f32(MCX_PAIR_LANES ? MCX_ACC_A(k) + MCX_ACC_B(k) : MCX_ACC_A(k)); \
             if (lane == 0u) wave_sums[wave][k] += (double)s_;                               \
         }                                                                                   \
     } while (0)
@@ -219,12 +222,12 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 #define MCX_FLUSH_ACC()                                                                     \
     do {                                                                                    \
         _Pragma("unroll") for (int k = 0; k < MCX_K; ++k)                                   \
-            sum[k] += MCX_PAIR_LANES ? (double)accA[k] + (double)MCX_ACC_B[k] : (double)accA[k]; \
+            sum[k] += MCX_PAIR_LANES ? (double)MCX_ACC_A(k) + (double)MCX_ACC_B(k) : (double)MCX_ACC_A(k); \
     } while (0)
 #endif
 #define MCX_ZERO_ACC()                                                                      \
     do {                                                                                    \
-        _Pragma("unroll") for (int k = 0; k < MCX_K; ++k) { accA[k] = 0.0f; MCX_ACC_B[k] = 0.0f; } \
+        _Pragma("unroll") for (int k = 0; k < MCX_K * MCX_ACC_S; ++k) acc[k] = 0.0f;                 \
     } while (0)
 
 #if MCX_RNG == 1
@@ -234,11 +237,11 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 #if MCX_DIST == MCX_DIST_NORMAL
         float z0, z1;
         mcx_box_muller(h_first, h_second, z0, z1);
-        mcx_accumulate(MCX_AFFINE(z0), is_tb, accA);
-        if (n_valid > 1u) mcx_accumulate(MCX_AFFINE(z1), is_tb, MCX_ACC_B);
+        mcx_accumulate<MCX_ACC_S>(MCX_AFFINE(z0), is_tb, acc);
+        if (n_valid > 1u) mcx_accumulate<MCX_ACC_S>(MCX_AFFINE(z1), is_tb, acc + (MCX_ACC_S - 1));
 #else
-        mcx_accumulate(mcx_draw(h_first, a, cdf_tb), is_tb, accA);
-        if (n_valid > 1u) mcx_accumulate(mcx_draw(h_second, a, cdf_tb), is_tb, MCX_ACC_B);
+        mcx_accumulate<MCX_ACC_S>(mcx_draw(h_first, a, cdf_tb), is_tb, acc);
+        if (n_valid > 1u) mcx_accumulate<MCX_ACC_S>(mcx_draw(h_second, a, cdf_tb), is_tb, acc + (MCX_ACC_S - 1));
 #endif
     };
     const u32 full_quads = a.loops_per_thread >> 2;          // calls whose four iterations all exist
@@ -279,8 +282,8 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
             st += 4u * MCX_STATE_STEP;
             float z0, z1;
             mcx_box_muller(h1, h2, z0, z1);
-            mcx_accumulate(MCX_AFFINE(z0), is_tb, accA);
-            mcx_accumulate(MCX_AFFINE(z1), is_tb, MCX_ACC_B);
+            mcx_accumulate<MCX_ACC_S>(MCX_AFFINE(z0), is_tb, acc);
+            mcx_accumulate<MCX_ACC_S>(MCX_AFFINE(z1), is_tb, acc + (MCX_ACC_S - 1));
         }
         MCX_FLUSH_ACC();
     }
@@ -292,7 +295,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         float z0, z1;
         mcx_box_muller(h1, h2, z0, z1);
         MCX_ZERO_ACC();
-        mcx_accumulate(MCX_AFFINE(z0), is_tb, accA);
+        mcx_accumulate<MCX_ACC_S>(MCX_AFFINE(z0), is_tb, acc);
         MCX_FLUSH_ACC();
     }
 #else
@@ -309,11 +312,11 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
             st += 2u * MCX_STATE_STEP;
             float xA = mcx_draw(hA, a, cdf_tb);
             float xB = mcx_draw(hB, a, cdf_tb);
-            mcx_accumulate(xA, is_tb, accA);
-            mcx_accumulate(xB, is_tb, MCX_ACC_B);
+            mcx_accumulate<MCX_ACC_S>(xA, is_tb, acc);
+            mcx_accumulate<MCX_ACC_S>(xB, is_tb, acc + (MCX_ACC_S - 1));
         }
         if (i < blk_end) {                                   // odd tail of the block
-            mcx_accumulate(mcx_draw(mcx_pcg_out(st), a, cdf_tb), is_tb, accA);
+            mcx_accumulate<MCX_ACC_S>(mcx_draw(mcx_pcg_out(st), a, cdf_tb), is_tb, acc);
             st += MCX_STATE_STEP;
             ++i;
         }
@@ -334,7 +337,9 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 #endif
 #undef MCX_FLUSH_ACC
 #undef MCX_ZERO_ACC
+#undef MCX_ACC_A
 #undef MCX_ACC_B
+#undef MCX_ACC_S
 }
 
 // =============================================================================================
@@ -436,7 +441,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
         cur_lq = take ? prop_lq : cur_lq;
         n_accept += take ? 1u : 0u;
         if (it > a.n_burnin) {                   // accumulate after every sampling step (shader_gen.rs:417-423)
-            mcx_eval_all(cur_x, 1.0f, acc);
+            mcx_eval_all<1>(cur_x, 1.0f, acc);
             if (++since_flush == 2u * MCX_FLUSH) {
 #pragma unroll
                 for (int k = 0; k < MCX_K; ++k) { sum[k] += (double)acc[k]; acc[k] = 0.0f; }
