@@ -48,6 +48,9 @@
 #ifndef MCX_FLUSH
 #define MCX_FLUSH 128            // units accumulated in f32 before folding into the f64 sums
 #endif
+#ifndef MCX_UNROLL
+#define MCX_UNROLL 1             // unroll factor of the sampling loops (tuning knob)
+#endif
 
 #define MCX_WAVES (MCX_BLOCK / 64)
 
@@ -276,6 +279,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         u32 blk_end = j + MCX_FLUSH;
         blk_end = blk_end < e_full ? blk_end : e_full;
         MCX_ZERO_ACC();
+#pragma unroll MCX_UNROLL
         for (; j < blk_end; ++j) {
             u32 h1 = mcx_pcg_out(st);
             u32 h2 = mcx_pcg_out(st + MCX_STATE_STEP);
@@ -306,6 +310,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         u32 blk_end = i + 2u * MCX_FLUSH;
         blk_end = blk_end < u1 ? blk_end : u1;
         MCX_ZERO_ACC();
+#pragma unroll MCX_UNROLL
         for (; i + 1u < blk_end; i += 2u) {
             u32 hA = mcx_pcg_out(st);
             u32 hB = mcx_pcg_out(st + MCX_STATE_STEP);
