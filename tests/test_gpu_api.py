@@ -228,3 +228,17 @@ def test_convenience_calls_reuse_the_device_engine():
     assert abs(r.values[0] - 1.0) < 0.02
     assert MonteCarloIntegrator()._engine is MonteCarloIntegrator()._engine
     assert per_call_ms < 5.0, per_call_ms
+
+
+def test_oversubscribed_reference_stream_warns():
+    from wgpu_montecarlo import MonteCarloIntegrator
+
+    mc = MonteCarloIntegrator()
+    with pytest.warns(UserWarning, match="exceeds the 2\\^32 counter space"):
+        r = mc.integrate([lambda x: x * x], D().normal(0.0, 1.0), n_samples=5_000_000_000)
+    assert abs(r.values[0] - 1.0) < 1e-3
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        MonteCarloIntegrator(rng="philox").integrate([lambda x: x * x], D().normal(0.0, 1.0), n_samples=5_000_000_000)

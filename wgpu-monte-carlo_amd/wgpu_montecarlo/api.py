@@ -219,6 +219,19 @@ class MonteCarloIntegrator:
             sums = distributed.all_reduce_host(g, sums)
         return sums / float(n_eff), n_eff
 
+    def _warn_if_oversubscribed(self, n_eff: int) -> None:
+        """The reference's counter hash has 2^32 distinct inputs. Beyond that many samples per call the estimator
+        stops converging: the stream is a finite population whose own mean is off by ~3e-5 (measured: E[x] on N(0,1)
+        is 10 sigma low at n = 1e11 and 33 sigma low at 1e12, tools/stream_quality.py / DESIGN.md 4.4)."""
+        if self._rng == runtime.RNG_PCG_REF and n_eff > (1 << 32) and not getattr(self, "_warned_stream", False):
+            import warnings
+
+            self._warned_stream = True
+            warnings.warn(
+                f"n_samples = {n_eff:.3g} exceeds the 2^32 counter space of the reference's random stream: accuracy "
+                f"saturates at about 3e-5 absolute. Pass rng='philox' to MonteCarloIntegrator for a 128-bit counter stream.",
+                UserWarning, stacklevel=3)
+
     def _rank_world(self):
         return (self._group.rank, self._group.world) if self._group is not None else (0, 1)
 
@@ -243,6 +256,7 @@ class MonteCarloIntegrator:
         values, n_eff = self._run(k * (2 if self._std_error else 1), lambda d_sums, stream: self._engine.integrate(
             mod, n_samples, seed, p1, p2, self._target_threads, cdf=cdf, rank=rank, world=world,
             d_sums=d_sums, stream=stream))
+        self._warn_if_oversubscribed(n_eff)
         return IntegrationResult(values[:k], n_samples, k, self._meta(n_eff, values, k))
 
     # ---- K2 ----------------------------------------------------------------------------------------
