@@ -15,6 +15,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch
 echo "pmc fetch rc=$?"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_write.err"
 echo "pmc write rc=$?"
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d "$OUT/pmc_grbm" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_grbm.err"
+echo "pmc grbm rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/configs_stats" -- python3 tools/run_configs.py --repeat 2 > "$OUT/configs_under_rocprof.jsonl" 2> "$OUT/configs_stats.err"
 echo "configs stats rc=$?"
 find "$OUT" -name "*kernel_stats.csv" -exec sh -c 'echo "== $1"; head -6 "$1"' _ {} \;
