@@ -130,12 +130,26 @@ typedef struct mcx_module_desc {
                                 * than ~2^32 uniforms */
     int32_t unit_params;       /* 1: the caller guarantees param1/param2 are the identity -- normal(0,1), uniform(0,1),
                                 * exponential(1) -- so the affine map of the sampler is not emitted (bit-identical results) */
-    int32_t second_moments;    /* 1: rows k..2k-1 of the result hold the sums of (f_i * w)^2 (standard errors); the
-                                * result then has 2k rows (integrate / importance sampling only) */
+    int32_t second_moments;    /* 1: rows k..2k-1 of the result hold the sums of (f_i * w)^2 (standard errors). MCMC
+                                * (k <= 16): additionally row 2k = accepted steps and rows 2k+1..3k hold the sums over
+                                * chains of (per-chain mean of f_i)^2 -- batch means for standard errors and effective
+                                * sample sizes. See mcx_result_rows. */
+    int32_t walk;              /* MCMC only. MCX_WALK_INDEPENDENT (0, the reference: x' ~ q, shader_gen.rs:466-539),
+                                * MCX_WALK_RANDOM (1): x' = x + d, d ~ q, log alpha = log p(x') - log p(x) + log q(-d) - log q(d),
+                                * MCX_WALK_RANDOM_SYMMETRIC (2): same with the q terms dropped (caller guarantees q(d) = q(-d)).
+                                * Random-walk proposals outside the target table (log p <= -100) are always rejected.
+                                * The reference leaves this open ("For now, we use independent proposal", shader_gen.rs:514). */
 } mcx_module_desc;
 
 #define MCX_RNG_PCG_REF 0
 #define MCX_RNG_PHILOX  1
+#define MCX_WALK_INDEPENDENT      0
+#define MCX_WALK_RANDOM           1
+#define MCX_WALK_RANDOM_SYMMETRIC 2
+
+/* Number of doubles a call with this module writes to sums_out / d_sums (<= 65), or a negative error:
+ * integrate: k (2k with second_moments); MCMC: k + 1 (3k + 1 with second_moments). */
+int  mcx_result_rows(const mcx_module_desc* desc);
 
 /* user_src: HIP C++ text defining `__device__ float user_func_i(float x)` for i < k (and
  * mcx_pdf_p / mcx_pdf_q when weight && !p_table / !q_table). */
@@ -197,10 +211,14 @@ typedef struct mcx_mcmc_params {
     const mcx_table* cdf;              /* custom proposal */
     const mcx_table* target_logpdf;    /* MCX_TABLE_LOGPDF, required */
     const mcx_table* proposal_logpdf;  /* MCX_TABLE_LOGPDF, required */
+    float    x0;                 /* random-walk modules: chains start at x0 + d_0 (d_0 = the iter-0 draw); else ignored */
+    uint32_t reserved;           /* 0 */
 } mcx_mcmc_params;
 
 /* sums_out[0..k) = sum over this rank's chains and all sampling steps of f_k(x_t);
- * sums_out[k] = number of accepted steps (burn-in included); n_eff_out = padded chains * n_steps. */
+ * sums_out[k] = number of accepted steps (burn-in included); n_eff_out = padded chains * n_steps.
+ * With desc.second_moments: [0..k) sums of f, [k..2k) sums of f^2, [2k] accepted steps,
+ * [2k+1..3k+1) sums over chains of (chain mean of f_i)^2. */
 int mcx_mcmc(mcx_engine* e, mcx_module* m, const mcx_mcmc_params* p,
              double* sums_out, uint64_t* n_eff_out);
 int mcx_mcmc_device(mcx_engine* e, mcx_module* m, const mcx_mcmc_params* p,

@@ -359,6 +359,12 @@ typedef struct {
     const float* proposal_logpdf;  /* interleaved */
     int32_t  guard;
     int32_t  rng;                  /* 0: reference stream; 1: libmcx's opt-in Philox stream (one call per step) */
+    int32_t  walk;                 /* 0: independent proposals (the reference). libmcx extensions (not in the reference, which
+                                    * says "For now, we use independent proposal", shader_gen.rs:514): 1: random walk
+                                    * x' = x + d, d ~ q, log alpha = log p(x') + log q(-d) - log p(x) - log q(d);
+                                    * 2: random walk, symmetric q: log alpha = log p(x') - log p(x). Random-walk proposals with
+                                    * log p(x') <= -100 (outside the target table) are always rejected. */
+    float    x0;                   /* random walk: chains start at x0 + d_0 */
 } orc_mcmc_args;
 
 /* Philox stream of libmcx for K3: call (idx, it, 1, 0), key (seed, 'MCX1'); outputs (0,1) -> proposal (z0 of the
@@ -397,39 +403,54 @@ static float mcmc_sample_q(const orc_mcmc_args* a, orc_bm_state* bm, uint32_t id
 
 /* out_ref[k]: the reference's f32 result. out_sum64[k]: f64 sums over all padded chains and sampling
  * steps; out_sum64[K] = accepted steps (burn-in included). trace (optional): [chains_to_trace][n_steps]
- * chain states after each sampling step, for evaluating arbitrary functions in numpy. */
+ * chain states after each sampling step, for evaluating arbitrary functions in numpy. out_diag (optional,
+ * 2K doubles): [0..K) sums of f^2, [K..2K) sums over chains of (f64 chain mean)^2 -- libmcx's batch-means rows. */
 int orc_mcmc(const orc_mcmc_args* a, const orc_fn* fns, int K, float* out_ref, double* out_sum64,
-             uint64_t* n_eff, float* trace, uint32_t chains_to_trace) {
+             uint64_t* n_eff, float* trace, uint32_t chains_to_trace, double* out_diag) {
     uint32_t cfg[4];
     orc_mcmc_dispatch_config(a->n_chains, a->target_threads, cfg);
     const uint32_t T = cfg[3];
     if (n_eff) *n_eff = (uint64_t)T * (uint64_t)a->n_steps;
     float* out = (float*)malloc((size_t)T * K * sizeof(float));
     double* s64 = (double*)calloc((size_t)T * (K + 1), sizeof(double));
-    if (!out || !s64) { free(out); free(s64); return -1; }
+    double* d64 = (double*)calloc((size_t)T * 2 * K, sizeof(double));
+    if (!out || !s64 || !d64) { free(out); free(s64); free(d64); return -1; }
 #pragma omp parallel for schedule(static)
     for (int64_t t = 0; t < (int64_t)T; ++t) {
         uint32_t idx = (uint32_t)t;
         orc_bm_state bm = {0, 0.0f};
         float current_x = a->rng == 1 ? mcmc_sample_q_philox(a, idx, 0u, NULL)
                                       : mcmc_sample_q(a, &bm, idx, 0u);         /* shader_gen.rs:445-463 */
+        if (a->walk) current_x += a->x0;
         float current_log_p = orc_table_lookup(a->target_logpdf, current_x, -100.0f);
         uint64_t accepted = 0;
         float acc[64];
-        double acc64[64];
-        for (int k = 0; k < K; ++k) { acc[k] = 0.0f; acc64[k] = 0.0; }
+        double acc64[64], sq64[64];
+        for (int k = 0; k < K; ++k) { acc[k] = 0.0f; acc64[k] = 0.0; sq64[k] = 0.0; }
         uint32_t total = a->n_burnin + a->n_steps;
         for (uint32_t it = 1u; it <= total; ++it) {                              /* burn-in: i+1 ; sampling: i+n_burnin+1 */
             uint32_t accept_hash = 0u;
-            float proposal_x = a->rng == 1 ? mcmc_sample_q_philox(a, idx, it, &accept_hash)
-                                           : mcmc_sample_q(a, &bm, idx, it + 1000000u);   /* shader_gen.rs:477-489 */
+            float draw = a->rng == 1 ? mcmc_sample_q_philox(a, idx, it, &accept_hash)
+                                     : mcmc_sample_q(a, &bm, idx, it + 1000000u);         /* shader_gen.rs:477-489 */
+            float proposal_x = a->walk ? current_x + draw : draw;
             float proposal_log_p_target = orc_table_lookup(a->target_logpdf, proposal_x, -100.0f);
-            float proposal_log_q = orc_table_lookup(a->proposal_logpdf, proposal_x, -100.0f);
-            float current_log_q = orc_table_lookup(a->proposal_logpdf, current_x, -100.0f);
-            float log_alpha = proposal_log_p_target + current_log_q - current_log_p - proposal_log_q;
+            float log_alpha;
+            if (a->walk == 0) {
+                float proposal_log_q = orc_table_lookup(a->proposal_logpdf, proposal_x, -100.0f);
+                float current_log_q = orc_table_lookup(a->proposal_logpdf, current_x, -100.0f);
+                log_alpha = proposal_log_p_target + current_log_q - current_log_p - proposal_log_q;   /* shader_gen.rs:526 */
+            } else if (a->walk == 1) {
+                float lq_fwd = orc_table_lookup(a->proposal_logpdf, draw, -100.0f);
+                float lq_back = orc_table_lookup(a->proposal_logpdf, -draw, -100.0f);
+                log_alpha = proposal_log_p_target + lq_back - current_log_p - lq_fwd;
+            } else {
+                log_alpha = proposal_log_p_target - current_log_p;
+            }
             float u = a->rng == 1 ? u_from_hash(accept_hash)
                                   : orc_random_uniform(a->seed + 999999u, idx, it);    /* shader_gen.rs:529 */
-            if (logf(u) < log_alpha) {
+            int take = logf(u) < log_alpha;
+            if (a->walk && !(proposal_log_p_target > -100.0f)) take = 0;   /* outside the target table: density 0 */
+            if (take) {
                 current_x = proposal_x;
                 current_log_p = proposal_log_p_target;
                 ++accepted;
@@ -439,6 +460,7 @@ int orc_mcmc(const orc_mcmc_args* a, const orc_fn* fns, int K, float* out_ref, d
                     float f = eval_fn(&fns[k], current_x);
                     acc[k] += f;
                     acc64[k] += (double)f;
+                    sq64[k] += (double)(f * f);
                 }
                 if (trace && idx < chains_to_trace) trace[(size_t)idx * a->n_steps + (it - a->n_burnin - 1u)] = current_x;
             }
@@ -448,7 +470,18 @@ int orc_mcmc(const orc_mcmc_args* a, const orc_fn* fns, int K, float* out_ref, d
             s64[(size_t)idx * (K + 1) + k] = acc64[k];
         }
         s64[(size_t)idx * (K + 1) + K] = (double)accepted;
+        for (int k = 0; k < K; ++k) {
+            double m = acc64[k] / (double)a->n_steps;
+            d64[(size_t)idx * 2 * K + k] = sq64[k];
+            d64[(size_t)idx * 2 * K + K + k] = m * m;
+        }
     }
+    if (out_diag)
+        for (int k = 0; k < 2 * K; ++k) {
+            double s = 0.0;
+            for (uint32_t t = 0; t < T; ++t) s += d64[(size_t)t * 2 * K + k];
+            out_diag[k] = s;
+        }
     for (int k = 0; k <= K; ++k) {
         float sum = 0.0f;
         double sum64 = 0.0;
@@ -459,7 +492,7 @@ int orc_mcmc(const orc_mcmc_args* a, const orc_fn* fns, int K, float* out_ref, d
         if (k < K && out_ref) out_ref[k] = sum / (float)T;                       /* lib.rs:420-428 */
         if (out_sum64) out_sum64[k] = sum64;
     }
-    free(out); free(s64);
+    free(out); free(s64); free(d64);
     return 0;
 }
 

@@ -59,9 +59,10 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0, help="scale n_samples / n_chains down for quick runs")
+    ap.add_argument("--rng", default="pcg_ref", choices=["pcg_ref", "philox"])
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
-    integ = MonteCarloIntegrator()
+    integ = MonteCarloIntegrator(rng=args.rng)
     f1 = lambda x: x
     f2 = lambda x: x**2
     f3 = lambda x: x**3
@@ -114,6 +115,31 @@ def main():
         sig = np.sqrt(np.array([5.0, 18.0]) * tau / res.meta["n_eff"])
         report("C4 MCMC K=2 bimodal target, N(0,2) proposal, 1048576 chains x (1000 + 10000) steps", res, [0, 5], sig,
                wall, steps, "MH steps/s")
+    if "C4RW" in only or "C4D" in only:
+        # extensions either side of C4: random-walk proposals and the batch-means diagnostics, at C4's size
+        chains = int(1_048_576 * args.scale)
+        target = Distribution.from_pdf(bimodal, support=(-10, 10))
+        variants = []
+        if "C4RW" in only:
+            variants.append(("C4RW random-walk MH, N(0,2.5) increments", MonteCarloIntegrator(rng=args.rng), "random_walk", Distribution.normal(0.0, 2.5)))
+        if "C4D" in only:
+            variants.append(("C4D independent MH + batch-means rows (std_error=True)", MonteCarloIntegrator(std_error=True, rng=args.rng),
+                             "independent", Distribution.normal(0.0, 2.0)))
+            variants.append(("C4D random-walk MH + batch-means rows (std_error=True)", MonteCarloIntegrator(std_error=True, rng=args.rng),
+                             "random_walk", Distribution.normal(0.0, 2.5)))
+        for name, mc, kind, prop in variants:
+            res, wall = timed(lambda: mc.integrate_mcmc([f1, f2], target, prop, n_steps=10_000, n_chains=chains,
+                                                        n_burnin=1000, proposal_kind=kind), max(1, args.repeat - 1))
+            steps = (res.meta["n_eff"] // 10_000) * 11_000
+            se = res.meta.get("std_error")
+            if se is None:
+                tau = 12.0                                   # measured by the C4D line below for these increments
+                se = np.sqrt(np.array([5.0, 18.0]) * tau / res.meta["n_eff"])
+            report(name + f", {chains} chains x (1000 + 10000) steps", res, [0, 5], se, wall, steps, "MH steps/s")
+            if "tau_int" in res.meta:
+                out[-1]["tau_int"] = res.meta["tau_int"].tolist()
+                out[-1]["ess"] = res.meta["ess"].tolist()
+                print(json.dumps(dict(config=name, tau_int=out[-1]["tau_int"], ess=out[-1]["ess"])), flush=True)
     if not only or "C5" in only:
         n = int(1e10 * args.scale)
         fns = [lambda x, k=k: x**k for k in range(1, 33)]      # bound defaults -> constants -> shared multiply chain

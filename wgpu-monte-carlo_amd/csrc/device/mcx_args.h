@@ -57,11 +57,11 @@ typedef struct McxMcmcArgs {
     mcx_u32 chain_count;        // chains in this launch
     mcx_u32 n_steps;
     mcx_u32 n_burnin;
-    mcx_u32 _pad0;
+    float   x0;                 // random-walk start (chains start at x0 + first draw)
     float   param1;             // proposal min / mean / lambda
     float   param2;             // proposal max / std
     McxTableDesc cdf;           // custom proposal sampling {cdf, x}
     McxTableDesc target_logpdf;   // {x, log p}
     McxTableDesc proposal_logpdf; // {x, log q}
-    double* partials;           // [gridDim.x][K+1]; column K = accepted-step count
+    double* partials;           // [gridDim.x][rows]; column MCX_K = accepted-step count
 } McxMcmcArgs;

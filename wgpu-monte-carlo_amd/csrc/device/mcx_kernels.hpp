@@ -51,6 +51,7 @@
 #ifndef MCX_UNROLL
 #define MCX_UNROLL 1             // unroll factor of the sampling loops (tuning knob)
 #endif
+static constexpr int mcx_unroll = MCX_UNROLL;   // a constant, not the macro, in the pragmas: they survive -save-temps
 
 #define MCX_WAVES (MCX_BLOCK / 64)
 
@@ -279,7 +280,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         u32 blk_end = j + MCX_FLUSH;
         blk_end = blk_end < e_full ? blk_end : e_full;
         MCX_ZERO_ACC();
-#pragma unroll MCX_UNROLL
+#pragma unroll mcx_unroll
         for (; j < blk_end; ++j) {
             u32 h1 = mcx_pcg_out(st);
             u32 h2 = mcx_pcg_out(st + MCX_STATE_STEP);
@@ -310,7 +311,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         u32 blk_end = i + 2u * MCX_FLUSH;
         blk_end = blk_end < u1 ? blk_end : u1;
         MCX_ZERO_ACC();
-#pragma unroll MCX_UNROLL
+#pragma unroll mcx_unroll
         for (; i + 1u < blk_end; i += 2u) {
             u32 hA = mcx_pcg_out(st);
             u32 hB = mcx_pcg_out(st + MCX_STATE_STEP);
@@ -348,8 +349,22 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 }
 
 // =============================================================================================
-// K3: independent-proposal Metropolis-Hastings, one chain per thread
+// K3: Metropolis-Hastings, one chain per thread. MCX_WALK 0: independent proposals x' ~ q (the reference);
+// 1: random walk x' = x + d, d ~ q, with the Hastings correction log q(-d) - log q(d); 2: random walk with a
+// symmetric q (no correction). MCX_SECOND_MOMENTS: accumulators also carry f^2, and every chain adds the
+// square of its own mean to rows MCX_K+1.. (batch means over chains -> standard error, effective sample size).
 // =============================================================================================
+#ifndef MCX_WALK
+#define MCX_WALK 0
+#endif
+#ifndef MCX_SECOND_MOMENTS
+#define MCX_SECOND_MOMENTS 0
+#endif
+#if MCX_SECOND_MOMENTS
+#define MCX_MCMC_ROWS (MCX_K + 1 + MCX_NF)
+#else
+#define MCX_MCMC_ROWS (MCX_K + 1)
+#endif
 #ifndef MCX_PROP_ITER_OFFSET
 #define MCX_PROP_ITER_OFFSET 1000000u      // shader_gen.rs:477-489
 #endif
@@ -376,7 +391,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     McxTable cdf_tb = mcx_stage_table(a.cdf, lds_off);
     McxTable lp_tb = mcx_stage_table(a.target_logpdf, lds_off);
     McxTable lq_tb = mcx_stage_table(a.proposal_logpdf, lds_off);
-    (void)cdf_tb;
+    (void)cdf_tb; (void)lq_tb;
     __syncthreads();
 
     // chain_count is a multiple of 256, so a wave is entirely inside or outside the launch's chain range
@@ -385,9 +400,9 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     const u32 idx = a.chain_begin + (active ? g : 0u);
     const u32 total_steps = active ? a.n_burnin + a.n_steps : 0u;     // wave-uniform
 
-    double sum[MCX_K + 1];
+    double sum[MCX_MCMC_ROWS];
 #pragma unroll
-    for (int k = 0; k <= MCX_K; ++k) sum[k] = 0.0;
+    for (int k = 0; k < MCX_MCMC_ROWS; ++k) sum[k] = 0.0;
     float acc[MCX_K];
 #pragma unroll
     for (int k = 0; k < MCX_K; ++k) acc[k] = 0.0f;
@@ -423,27 +438,53 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     cur_x = mcx_draw_proposal(mcx_pcg_out(mcx_state(a.seed, idx, 0u)), a, cdf_tb);
     u32 st_prop = mcx_state(a.seed, idx, 1u + MCX_PROP_ITER_OFFSET);
 #endif
+#if MCX_WALK
+    cur_x += a.x0;                                            // chains start at x0 + d_0
+#endif
     float cur_lp = mcx_table_lookup(lp_tb, cur_x, -100.0f);
+#if MCX_WALK == 0
     float cur_lq = mcx_table_lookup(lq_tb, cur_x, -100.0f);   // pure function of cur_x: cached
+#endif
 #if MCX_RNG == 0
     u32 st_acc = mcx_state(a.seed + MCX_ACCEPT_SEED_OFFSET, idx, 1u);
 #endif
 
-    // One Metropolis-Hastings step with proposal prop_x and accept hash ha (shader_gen.rs:511-537);
+    // One Metropolis-Hastings step with the proposal draw and accept hash ha (shader_gen.rs:511-537);
     // `it` is wave-uniform.
-    auto mh_step_h = [&](u32 it, float prop_x, u32 ha) {
+    auto mh_step_h = [&](u32 it, float draw, u32 ha) {
+#if MCX_WALK == 0
+        const float prop_x = draw;
         float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
         float prop_lq = mcx_table_lookup(lq_tb, prop_x, -100.0f);
         float log_alpha = prop_lp + cur_lq - cur_lp - prop_lq;                     // shader_gen.rs:526
+#elif MCX_WALK == 1
+        const float prop_x = cur_x + draw;
+        float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
+        float lq_fwd = mcx_table_lookup(lq_tb, draw, -100.0f);                     // q(x' | x) = q(d)
+        float lq_back = mcx_table_lookup(lq_tb, -draw, -100.0f);                   // q(x | x') = q(-d)
+        float log_alpha = prop_lp + lq_back - cur_lp - lq_fwd;
+#else
+        const float prop_x = cur_x + draw;
+        float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
+        float log_alpha = prop_lp - cur_lp;
+#endif
 #if MCX_PRECISE_SAMPLER
         float ln_u = logf(mcx_u01_closed(ha));
 #else
         float ln_u = (__builtin_amdgcn_logf((float)ha) - 32.0f) * 0x1.62e43p-1f;   // h = 0 -> -inf: accept
 #endif
+#if MCX_WALK
+        // a proposal outside the target table has density 0, not e^-100: without this a chain that starts outside
+        // would see a flat landscape, accept every move and diffuse away instead of waiting for a move back inside
+        const bool take = (ln_u < log_alpha) & (prop_lp > -100.0f);
+#else
         const bool take = ln_u < log_alpha;
+#endif
         cur_x = take ? prop_x : cur_x;
         cur_lp = take ? prop_lp : cur_lp;
+#if MCX_WALK == 0
         cur_lq = take ? prop_lq : cur_lq;
+#endif
         n_accept += take ? 1u : 0u;
         if (it > a.n_burnin) {                   // accumulate after every sampling step (shader_gen.rs:417-423)
             mcx_eval_all<1>(cur_x, 1.0f, acc);
@@ -501,8 +542,15 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #pragma unroll
     for (int k = 0; k < MCX_K; ++k) sum[k] += (double)acc[k];
     sum[MCX_K] = (double)n_accept;
+#if MCX_SECOND_MOMENTS
+    {
+        const double inv_steps = 1.0 / (double)a.n_steps;    // inactive waves: sums are zero
+#pragma unroll
+        for (int k = 0; k < MCX_NF; ++k) { const double m = sum[k] * inv_steps; sum[MCX_K + 1 + k] = m * m; }
+    }
+#endif
 
-    mcx_block_reduce_store<MCX_K + 1>(sum, a.partials);
+    mcx_block_reduce_store<MCX_MCMC_ROWS>(sum, a.partials);
 }
 
 // =============================================================================================

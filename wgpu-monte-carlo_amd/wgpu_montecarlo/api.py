@@ -148,6 +148,8 @@ class MonteCarloIntegrator:
             128-bit counter (four iterations per call for integrate / importance sampling, one call per MH step).
         std_error: also accumulate sum (f_k w)^2 in the same pass; integrate / importance-sampling results then
             carry result.meta["std_error"][k] = sqrt((E[(f w)^2] - E[f w]^2) / N_eff) (extension; K <= 32).
+            integrate_mcmc results carry batch-means standard errors over the independent chains plus
+            meta["tau_int"] and meta["ess"] (K <= 16).
     """
 
     def __init__(self, target_threads: Optional[int] = None, device: Optional[int] = None, process_group=None,
@@ -219,7 +221,7 @@ class MonteCarloIntegrator:
             sums = distributed.all_reduce_host(g, sums)
         return sums / float(n_eff), n_eff
 
-    def _warn_if_oversubscribed(self, n_eff: int) -> None:
+    def _warn_if_oversubscribed(self, n_eff: int, what: str = "n_samples") -> None:
         """The reference's counter hash has 2^32 distinct inputs. Beyond that many samples per call the estimator
         stops converging: the stream is a finite population whose own mean is off by ~3e-5 (measured: E[x] on N(0,1)
         is 10 sigma low at n = 1e11 and 33 sigma low at 1e12, tools/stream_quality.py / DESIGN.md 4.4)."""
@@ -228,7 +230,7 @@ class MonteCarloIntegrator:
 
             self._warned_stream = True
             warnings.warn(
-                f"n_samples = {n_eff:.3g} exceeds the 2^32 counter space of the reference's random stream: accuracy "
+                f"{what} = {n_eff:.3g} exceeds the 2^32 counter space of the reference's random stream: accuracy "
                 f"saturates at about 3e-5 absolute. Pass rng='philox' to MonteCarloIntegrator for a 128-bit counter stream.",
                 UserWarning, stacklevel=3)
 
@@ -301,8 +303,18 @@ class MonteCarloIntegrator:
     # ---- K3 ----------------------------------------------------------------------------------------
     def integrate_mcmc(self, functions: List[FunctionLike], target_distribution: Distribution,
                        proposal_distribution: Distribution, n_steps: int = 10_000, n_chains: int = 1024,
-                       n_burnin: int = 1_000, seed: int = 42) -> IntegrationResult:
-        """E_p[f_k(X)] by independent-proposal Metropolis-Hastings, one chain per logical thread."""
+                       n_burnin: int = 1_000, seed: int = 42, proposal_kind: str = "independent",
+                       initial_state: float = 0.0) -> IntegrationResult:
+        """E_p[f_k(X)] by Metropolis-Hastings, one chain per logical thread.
+
+        proposal_kind="independent" (default) is the reference's sampler: x' ~ proposal_distribution
+        (shader_gen.rs:466-539). proposal_kind="random_walk" (extension; the reference leaves it open at
+        shader_gen.rs:514) draws the *increment* from proposal_distribution: x' = x + d, chains start at
+        initial_state + d_0; the Hastings correction log q(-d) - log q(d) is applied unless the increment
+        distribution is symmetric about 0 (normal(0, s), uniform(-w, w)). With std_error=True the result carries
+        meta["std_error"] (batch means over chains), meta["ess"] and meta["tau_int"] per function (K <= 16)."""
+        if proposal_kind not in ("independent", "random_walk"):
+            raise ValueError(f"Unknown proposal_kind: {proposal_kind!r} (expected 'independent' or 'random_walk')")
         if len(functions) == 0:
             raise ValueError("At least one function is required")
         if n_steps <= 0:
@@ -323,18 +335,40 @@ class MonteCarloIntegrator:
         code, p1, p2 = _dist_params(proposal_distribution)
         cdf = self._cdf_table(proposal_distribution)
         lds_ok = self._lds_bytes(cdf, t_table, q_table) <= _LDS_TABLE_BUDGET
+        walk = runtime.WALK_INDEPENDENT
+        if proposal_kind == "random_walk":
+            symmetric = (code == runtime.DIST_NORMAL and p1 == 0.0) or (code == runtime.DIST_UNIFORM and p1 == -p2)
+            walk = runtime.WALK_RANDOM_SYMMETRIC if symmetric else runtime.WALK_RANDOM
         desc = runtime.make_desc(runtime.KIND_MCMC, len(functions), code, guard_endpoints=self._guard,
                                  precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng,
-                                 unit_params=_unit_params(code, p1, p2))
+                                 unit_params=_unit_params(code, p1, p2), second_moments=self._std_error, walk=walk)
         mod = self._engine.module(user_src, desc)
         rank, world = self._rank_world()
         k = len(functions)
-        values, n_eff = self._run(k + 1, lambda d_sums, stream: self._engine.mcmc(
+        rows = runtime.result_rows(desc)
+        values, n_eff = self._run(rows, lambda d_sums, stream: self._engine.mcmc(
             mod, n_steps, n_chains, n_burnin, seed, p1, p2, t_table, q_table,
-            target_threads=self._target_threads, cdf=cdf, rank=rank, world=world, d_sums=d_sums, stream=stream))
+            target_threads=self._target_threads, cdf=cdf, rank=rank, world=world, d_sums=d_sums, stream=stream,
+            x0=float(initial_state)))
         meta = self._meta(n_eff)
         total_chains = n_eff // n_steps
-        meta["accept_rate"] = float(values[k]) * n_eff / (float(total_chains) * (n_steps + n_burnin))
+        # chains whose counters collide replay each other's random numbers with a time shift: the estimate stays
+        # consistent but the chains are no longer independent (measured at C4's size with random-walk proposals:
+        # 5-7 batch-means standard errors off with the reference stream, 0.4 with Philox)
+        self._warn_if_oversubscribed(2 * total_chains * (n_steps + n_burnin), "uniform draws (chains x steps x 2)")
+        row_accept = 2 * k if self._std_error else k
+        meta["accept_rate"] = float(values[row_accept]) * n_eff / (float(total_chains) * (n_steps + n_burnin))
+        meta["proposal_kind"] = proposal_kind
+        if self._std_error:
+            # batch means with one batch per chain: chains are independent, so the spread of their means measures
+            # the Monte-Carlo error whatever the autocorrelation inside a chain is
+            mean = values[:k]
+            with np.errstate(invalid="ignore", divide="ignore"):
+                var_f = np.maximum(values[k:2 * k] - mean ** 2, 0.0)
+                var_between = np.maximum(values[2 * k + 1:3 * k + 1] * (n_eff / float(total_chains)) - mean ** 2, 0.0)
+                meta["std_error"] = np.sqrt(var_between / float(max(total_chains - 1, 1)))
+                meta["tau_int"] = n_steps * var_between / var_f
+                meta["ess"] = float(n_eff) / meta["tau_int"]
         return IntegrationResult(values[:k], n_chains * n_steps, k, meta)
 
     # ---- prepared (asynchronous) form of K1 ---------------------------------------------------------

@@ -23,6 +23,7 @@ DIST_UNIFORM, DIST_NORMAL, DIST_EXPONENTIAL, DIST_CUSTOM = 0, 1, 2, 3
 TABLE_CDF, TABLE_PDF, TABLE_LOGPDF = 0, 1, 2
 KIND_INTEGRATE, KIND_MCMC = 0, 1
 RNG_PCG_REF, RNG_PHILOX = 0, 1
+WALK_INDEPENDENT, WALK_RANDOM, WALK_RANDOM_SYMMETRIC = 0, 1, 2
 RNG_CODES = {"pcg_ref": RNG_PCG_REF, "philox": RNG_PHILOX}
 
 E_INVALID, E_RUNTIME, E_COMPILE, E_NODEVICE = -1, -2, -3, -4
@@ -44,7 +45,8 @@ class ModuleDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("dist_type", C.c_int32), ("weight", C.c_int32),
                 ("p_table", C.c_int32), ("q_table", C.c_int32), ("guard_endpoints", C.c_int32),
                 ("precise_sampler", C.c_int32), ("block", C.c_int32), ("tables_lds", C.c_int32),
-                ("rng", C.c_int32), ("unit_params", C.c_int32), ("second_moments", C.c_int32)]
+                ("rng", C.c_int32), ("unit_params", C.c_int32), ("second_moments", C.c_int32),
+                ("walk", C.c_int32)]
 
 
 class IntegrateParams(C.Structure):
@@ -57,7 +59,8 @@ class McmcParams(C.Structure):
     _fields_ = [("n_steps", C.c_uint32), ("n_chains", C.c_uint32), ("n_burnin", C.c_uint32),
                 ("target_threads", C.c_int64), ("seed", C.c_uint32), ("param1", C.c_float),
                 ("param2", C.c_float), ("rank", C.c_uint32), ("world", C.c_uint32),
-                ("cdf", C.c_void_p), ("target_logpdf", C.c_void_p), ("proposal_logpdf", C.c_void_p)]
+                ("cdf", C.c_void_p), ("target_logpdf", C.c_void_p), ("proposal_logpdf", C.c_void_p),
+                ("x0", C.c_float), ("reserved", C.c_uint32)]
 
 
 # every symbol include/mcx.h declares (tests check that the library exports all of them)
@@ -65,7 +68,7 @@ EXPORTED_SYMBOLS = [
     "mcx_version", "mcx_last_error", "mcx_hip_runtime", "mcx_dispatch_config", "mcx_mcmc_dispatch_config", "mcx_shard_integrate",
     "mcx_shard_units", "mcx_shard_chains", "mcx_device_count", "mcx_engine_create", "mcx_engine_destroy", "mcx_engine_device",
     "mcx_engine_last_kernel_ms", "mcx_engine_last_launch", "mcx_engine_set_target_threads", "mcx_module_build",
-    "mcx_module_precompile", "mcx_module_source", "mcx_free", "mcx_module_release", "mcx_cache_dir",
+    "mcx_module_precompile", "mcx_result_rows", "mcx_module_source", "mcx_free", "mcx_module_release", "mcx_cache_dir",
     "mcx_table_create", "mcx_table_release", "mcx_table_info", "mcx_integrate", "mcx_integrate_device",
     "mcx_mcmc", "mcx_mcmc_device",
 ]
@@ -134,6 +137,7 @@ def load():
         L.mcx_engine_set_target_threads.argtypes = [vp, u32]
         L.mcx_module_build.argtypes = [vp, C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(vp)]
         L.mcx_module_precompile.argtypes = [C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(C.c_int)]
+        L.mcx_result_rows.argtypes = [C.POINTER(ModuleDesc)]
         L.mcx_module_source.argtypes = [C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(vp)]
         L.mcx_free.argtypes = [vp]
         L.mcx_free.restype = None
@@ -199,11 +203,20 @@ def shard_chains(total_chains: int, rank: int, world: int):
 def make_desc(kind: int, k: int, dist_type: int, weight: bool = False, p_table: bool = False,
               q_table: bool = False, guard_endpoints: bool = True, precise_sampler: bool = False,
               block: int = 0, tables_lds: bool = True, rng: int = 0, second_moments: bool = False,
-              unit_params: bool = False) -> ModuleDesc:
+              unit_params: bool = False, walk: int = 0) -> ModuleDesc:
     if not block and os.environ.get("MCX_BLOCK"):        # tuning knob
         block = int(os.environ["MCX_BLOCK"])
     return ModuleDesc(kind, k, dist_type, int(weight), int(p_table), int(q_table), int(guard_endpoints),
-                      int(precise_sampler), int(block), int(tables_lds), int(rng), int(unit_params), int(second_moments))
+                      int(precise_sampler), int(block), int(tables_lds), int(rng), int(unit_params), int(second_moments),
+                      int(walk))
+
+
+def result_rows(desc: ModuleDesc) -> int:
+    """Doubles a call with this module writes (include/mcx.h: mcx_result_rows)."""
+    rows = int(load().mcx_result_rows(C.byref(desc)))
+    if rows < 0:
+        check(rows)
+    return rows
 
 
 def module_source(user_src: str, desc: ModuleDesc) -> str:
@@ -387,17 +400,18 @@ class Engine:
     def mcmc(self, mod: Module, n_steps: int, n_chains: int, n_burnin: int, seed: int, param1: float,
              param2: float, target_logpdf: Table, proposal_logpdf: Table, target_threads: Optional[int] = None,
              cdf: Optional[Table] = None, rank: int = 0, world: int = 1, d_sums: Optional[int] = None,
-             stream: Optional[int] = None):
-        """Returns (sums float64[K+1] (last = accepted steps) or None, n_eff)."""
+             stream: Optional[int] = None, x0: float = 0.0):
+        """Returns (sums float64[result_rows(desc)] (row k, or 2k with second moments = accepted steps) or None,
+        n_eff)."""
         p = McmcParams(int(n_steps), int(n_chains), int(n_burnin), int(target_threads or 0),
                        int(seed) & 0xFFFFFFFF, float(param1), float(param2), int(rank), int(world),
-                       self._ptr(cdf), self._ptr(target_logpdf), self._ptr(proposal_logpdf))
+                       self._ptr(cdf), self._ptr(target_logpdf), self._ptr(proposal_logpdf), float(x0), 0)
         n_eff = C.c_uint64(0)
         if d_sums is not None:
             check(load().mcx_mcmc_device(self._h, mod._h, C.byref(p), C.c_void_p(d_sums),
                                          _stream_arg(stream), C.byref(n_eff)))
             return None, int(n_eff.value)
-        sums = np.zeros(mod.desc.k + 1, dtype=np.float64)
+        sums = np.zeros(result_rows(mod.desc), dtype=np.float64)
         check(load().mcx_mcmc(self._h, mod._h, C.byref(p), sums.ctypes.data_as(C.POINTER(C.c_double)),
                               C.byref(n_eff)))
         return sums, int(n_eff.value)
