@@ -66,9 +66,11 @@ def cpu_baseline(target_seconds: float):
     t0 = time.perf_counter()
     pilot = oracle.integrate(fns, oracle.NORMAL, 0.0, 1.0, n_samples=50_000_000, seed=7)
     rate = pilot["n_eff"] / (time.perf_counter() - t0)
-    n_samples = int(min(max(rate * target_seconds, 1e8), 1e10))
+    # at most 4e9: inside the 2^32 counter space of the reference stream; guard=1 as libmcx runs it (the strict
+    # reference takes log(0) for the one hash value 0, which a slice this large does meet)
+    n_samples = int(min(max(rate * target_seconds, 1e8), 4e9))
     t0 = time.perf_counter()
-    res = oracle.integrate(fns, oracle.NORMAL, 0.0, 1.0, n_samples=n_samples, seed=42)
+    res = oracle.integrate(fns, oracle.NORMAL, 0.0, 1.0, n_samples=n_samples, seed=42, guard=1)
     dt = time.perf_counter() - t0
     return dict(value=res["n_eff"] / dt, unit="samples/s", cores=oracle.num_threads(), kind="port",
                 sample=f"K=4 moments on N(0,1), n={n_samples:.2e} (N_eff {res['n_eff']}) of the 1e9-per-GPU-per-step workload, "

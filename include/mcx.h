@@ -139,6 +139,9 @@ typedef struct mcx_module_desc {
                                 * MCX_WALK_RANDOM_SYMMETRIC (2): same with the q terms dropped (caller guarantees q(d) = q(-d)).
                                 * Random-walk proposals outside the target table (log p <= -100) are always rejected.
                                 * The reference leaves this open ("For now, we use independent proposal", shader_gen.rs:514). */
+    int32_t cell_tables;       /* 1: the caller guarantees every PDF / log-PDF table bound to this module has the
+                                * slope-intercept cell form (mcx_table_has_cells); the lookup is then compiled as one
+                                * 8-byte read + one FMA with no search path (checked at launch; not with precise_sampler) */
 } mcx_module_desc;
 
 #define MCX_RNG_PCG_REF 0
@@ -171,6 +174,14 @@ int  mcx_table_create(mcx_engine* e, int kind, const float* keys, const float* v
 void mcx_table_release(mcx_table* t);
 /* Host-side analysis results (also usable in tests): uniform-grid flag and guide-table bits. */
 int  mcx_table_info(const mcx_table* t, uint32_t* n, float* inv_dk, uint32_t* guide_bits);
+/* Host-side, no GPU needed: the per-cell line coefficients a PDF / log-PDF table on a strict f32-linspace grid is
+ * stored with (value(x) = slope * x + intercept on cell c: the interpolant of src/distribution.rs:181-223 / 375-417 in
+ * slope-intercept form, coefficients from f64). Returns 1 and fills cells_out[2 * (n - 1)] = {intercept, slope} per
+ * cell (cells_out may be NULL), or 0 when the keys are not such a grid -- lookups then run the verified / searched
+ * key-value path. */
+/* 1 if the table was stored with slope-intercept cells (PDF / log-PDF kinds on a strict f32-linspace grid), else 0. */
+int  mcx_table_has_cells(const mcx_table* t);
+int  mcx_table_cells(const float* keys, const float* values, uint32_t n, float* cells_out);
 
 /* ------------------------------------------------------------------------------------------
  * Integration -- replaces _core.MonteCarloIntegrator.integrate (src/lib.rs:47-141) and

@@ -151,3 +151,33 @@ def test_product_never_imports_the_oracle():
     for path in list(pkg.rglob("*.py")) + list(pkg.rglob("*.cpp")) + list(pkg.rglob("*.hpp")) + list(pkg.rglob("*.h")):
         text = path.read_text()
         assert "import oracle" not in text and "liboracle" not in text and "mcx_oracle" not in text, path
+
+
+def test_table_cells_strict_grid_and_accuracy():
+    """mcx_table_cells: slope-intercept cells only for f32-linspace keys; same interpolant as the reference's lookup."""
+    import oracle
+
+    xs = np.linspace(-10.0, 10.0, 2048).astype(np.float32)
+    vs = (-0.5 * xs.astype(np.float64) ** 2 - 0.9).astype(np.float32)
+    cells = rt.table_cells(xs, vs)
+    assert cells is not None and cells.shape == (2047, 2)
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-10, 10, 4000).astype(np.float32)
+    inv_dk = np.float32(2047 / 20.0)
+    g = np.clip((x - xs[0]) * inv_dk, 0, 2046).astype(np.int64)
+    got = (cells[g, 1].astype(np.float64) * x + cells[g, 0]).astype(np.float32)      # fmaf
+    want = np.array([oracle.table_lookup(xs, vs, float(v), -100.0) for v in x])
+    assert np.max(np.abs(got - want)) < 2e-5            # |v| up to 50: a few f32 ulps of the table values
+    # nearly uniform is not enough (the arithmetic cell guess is not verified on the cell path)
+    bumpy = xs.copy()
+    bumpy[1000] += 0.1 * (xs[1] - xs[0])
+    assert rt.table_cells(bumpy, vs) is None
+    assert rt.table_cells(np.array([0.0, 1.0, 3.0], np.float32), np.zeros(3, np.float32)) is None
+    assert rt.table_cells(np.array([1.0, 1.0], np.float32), np.zeros(2, np.float32)) is None
+    # reference-built tables are strict grids
+    from wgpu_montecarlo import Distribution
+
+    tx, tl = Distribution.normal(0.0, 2.0).get_log_pdf_table()
+    assert rt.table_cells(tx, tl) is not None
+    d = Distribution.from_pdf_table(np.linspace(0, 10, 512), np.exp(-np.linspace(0, 10, 512)))
+    assert rt.table_cells(d._x_table, d._pdf_table) is not None

@@ -167,6 +167,59 @@ def test_importance_sampling_both_tables_nonuniform_grid(integrator):
     assert abs(res.values[1] - 1.0) < 0.02
 
 
+@pytest.mark.parametrize("math_mode", ["default", "precise"])
+def test_importance_sampling_nearly_uniform_grid(math_mode):
+    """A target table whose keys are only *nearly* a linspace is not given slope-intercept cells
+    (mcx_table_cells = 0), so the module is built without cell_tables and both lookups run the key/value form
+    (guessed-and-verified for the target, also for the strict-grid proposal); math="precise" never uses cells."""
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+    from wgpu_montecarlo import runtime as rt
+
+    rng = np.random.default_rng(0)
+    xt = np.linspace(-4, 4, 700)
+    xt[1:-1] += rng.uniform(-0.2, 0.2, 698) * (xt[1] - xt[0])
+    target = Distribution.from_pdf_table(xt, np.exp(-0.5 * xt * xt) / np.sqrt(2 * np.pi))
+    xq = np.linspace(-9, 9, 1200)
+    proposal = Distribution.from_pdf_table(xq, np.exp(-0.5 * (xq / 2) ** 2) / (2 * np.sqrt(2 * np.pi)))
+    assert rt.table_cells(target._x_table, target._pdf_table) is None
+    assert rt.table_cells(proposal._x_table, proposal._pdf_table) is not None
+    mc = MonteCarloIntegrator(math=math_mode)
+    res = mc.integrate_importance_sampling([lambda x: x, lambda x: x**2], target, proposal, n_samples=1_000_000, seed=5)
+    ref = oracle.integrate([(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2)], oracle.CUSTOM, n_samples=1_000_000,
+                           seed=5, guard=1, cdf_table=proposal._cdf_table, x_table=proposal._x_table,
+                           p=(oracle.PDF_TABLE, target._x_table, target._pdf_table),
+                           q=(oracle.PDF_TABLE, proposal._x_table, proposal._pdf_table))
+    ok, msg = close(res.values, ref["sums"] / ref["n_eff"], tol=2e-6 if math_mode == "precise" else TOL)
+    assert ok, msg
+    assert abs(res.values[1] - 1.0) < 0.02
+    assert not mc._cell_tables(mc._table(rt.TABLE_PDF, target._x_table, target._pdf_table))
+
+
+def test_cell_tables_module_rejects_a_table_without_cells(integrator):
+    """desc.cell_tables is a promise about the tables bound at launch; libmcx checks it (MCX_E_INVALID)."""
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo import runtime as rt
+    from wgpu_montecarlo.api import functions_to_hip
+
+    eng = integrator._engine
+    xs = np.linspace(-3, 3, 300)
+    strict = integrator._table(rt.TABLE_PDF, xs, np.exp(-0.5 * xs * xs))
+    bumpy_x = xs.copy()
+    bumpy_x[100] += 0.2 * (xs[1] - xs[0])
+    bumpy = integrator._table(rt.TABLE_PDF, bumpy_x, np.exp(-0.5 * bumpy_x * bumpy_x))
+    assert strict.has_cells and not bumpy.has_cells
+    mod = eng.module(functions_to_hip(MOMENTS[:1]), rt.make_desc(rt.KIND_INTEGRATE, 1, rt.DIST_NORMAL, weight=True,
+                                                                   p_table=True, q_table=True, cell_tables=True))
+    wide = np.linspace(-8, 8, 500)
+    q = integrator._table(rt.TABLE_PDF, wide, np.exp(-0.5 * wide * wide))
+    sums, n_eff = eng.integrate(mod, 100_000, 1, 0.0, 1.0, target_pdf=strict, proposal_pdf=q)
+    assert np.isfinite(sums[0])
+    with pytest.raises(ValueError, match="no cell form"):
+        eng.integrate(mod, 100_000, 1, 0.0, 1.0, target_pdf=bumpy, proposal_pdf=q)
+    with pytest.raises(ValueError, match="precise_sampler"):
+        rt.module_source("", rt.make_desc(rt.KIND_INTEGRATE, 1, rt.DIST_NORMAL, cell_tables=True, precise_sampler=True))
+
+
 def _mcmc_oracle(target, proposal, code, p1, p2, **kw):
     tx, tl = target.get_log_pdf_table()
     px, pl = proposal.get_log_pdf_table()

@@ -60,6 +60,21 @@ MCX_DEV u32 mcx_pcg_out(u32 state) {
     return (word >> 22u) ^ word;
 }
 
+// The hash output that only feeds the Box-Muller angle. With MCX_THETA_FROM_BITS the angle is the top 23 bits of
+// the word (see mcx_box_muller); the final xorshift `^ (word >> 22)` changes only the lowest of those 23 bits
+// (bit 9 ^= bit 31), i.e. the angle by at most 2^-23 rev, the same size as the truncation itself -- so it is not
+// computed: two VALU instructions fewer per pair. MCX_PRECISE_SAMPLER / MCX_THETA_FROM_BITS=0 use the full hash.
+#ifndef MCX_THETA_FROM_BITS
+#define MCX_THETA_FROM_BITS 1
+#endif
+MCX_DEV u32 mcx_pcg_angle(u32 state) {
+#if MCX_PRECISE_SAMPLER || !MCX_THETA_FROM_BITS
+    return mcx_pcg_out(state);
+#else
+    return ((state >> ((state >> 28u) + 4u)) ^ state) * MCX_PCG_OUTMUL;
+#endif
+}
+
 // float(h) / 4294967295.0 in f32: the divisor literal rounds to 2^32, so this is an exact scale.
 // Closed interval: 0 iff h == 0, 1.0 iff h >= 0xFFFFFF80 (distribution.rs:72).
 MCX_DEV float mcx_u01_closed(u32 h) { return (float)h * 0x1.0p-32f; }
@@ -117,12 +132,23 @@ MCX_DEV float mcx_sample_exponential(float u, float lambda) {
 
 // One Box-Muller pair from two hash outputs. z0 = r cos(2 pi u2), z1 = r sin(2 pi u2), r = sqrt(-2 ln u1).
 // v_sin_f32 / v_cos_f32 take their argument in revolutions, so u2 feeds them directly.
+//
+// MCX_THETA_FROM_BITS (default, not with MCX_PRECISE_SAMPLER): the angle is handed to v_sin/v_cos as
+// 1 + (h2 >> 9) * 2^-23 revolutions in [1, 2) -- the top 23 bits of h2 dropped into the mantissa of 1.0f by ONE
+// v_alignbit_b32 (the hardware reduces the integer part itself) instead of v_cvt_f32_u32 (half rate) + v_mul_f32.
+// The angle is truncated to 2^-23 rev instead of rounded to 24 significant bits: a per-sample difference of
+// <= 7.5e-7 rad, below the error of v_sin_f32 itself, and a fixed rotation of the (z0, z1) pair on average.
+// h2 may be the angle word of mcx_pcg_angle.
 MCX_DEV void mcx_box_muller(u32 h1, u32 h2, float& z0, float& z1) {
     float f1 = (float)h1;
 #if MCX_GUARD_ENDPOINTS
     f1 = fmaxf(f1, 0.5f);                         // h == 0 -> u1 = 2^-33 instead of log(0)
 #endif
+#if MCX_PRECISE_SAMPLER || !MCX_THETA_FROM_BITS
     float u2 = (float)h2 * 0x1.0p-32f;
+#else
+    float u2 = __builtin_bit_cast(float, __builtin_amdgcn_alignbit(0x7Fu, h2, 9u));
+#endif
 #if MCX_PRECISE_SAMPLER
     float u1 = f1 * 0x1.0p-32f;
     float r = sqrtf(-2.0f * logf(u1));
@@ -147,6 +173,16 @@ MCX_DEV void mcx_box_muller(u32 h1, u32 h2, float& z0, float& z1) {
 // for PDF / log-PDF lookup key = x, value = pdf. The reference's buffers hold the same numbers as
 // [n, x0, v0, x1, v1, ...] (engine.rs:533-564) resp. two separate arrays (engine.rs:235-295).
 
+#ifndef MCX_CELL_TABLES
+#define MCX_CELL_TABLES 0
+#endif
+
+// Cell lookups: keep the LDS read unconditional (1) or let the compiler sink it into an exec-masked block for the
+// in-range lanes (0). Measured: K2 (C3) 0.99 ms vs 1.07 ms in favour of 1, K3 (C4) 13.55 ms vs 13.4 ms in favour of 0.
+#ifndef MCX_LOOKUP_BRANCHLESS
+#define MCX_LOOKUP_BRANCHLESS (MCX_KIND == 0)
+#endif
+
 struct McxTable {
     const float2* kv;     // LDS or global
     u32   n;
@@ -154,6 +190,7 @@ struct McxTable {
     float inv_dk;         // (n-1)/(k[n-1]-k[0]) when the keys are a uniform grid, else 0
     const u32* guide;     // CDF only: guide[b] = lo | hi << 16, the search window of bucket b, or null
     u32   guide_bits;     // number of buckets G = 1 << guide_bits
+    const float2* cells;  // PDF / log-PDF on a strict grid: cells[c] = {intercept, slope} of cell c, else null (then kv is set)
 };
 
 // a / b with v_rcp_f32 (<= 1.5 ulp): used for the interpolation weights and the importance ratio.
@@ -255,10 +292,35 @@ MCX_COLD float mcx_table_lookup_cold(const float2* kv, u32 n, float x, int g) {
     return mcx_lerp_cell(kv[low], kv[low + 1u], x);
 }
 
+//
+// Strict f32-linspace grids (the tables Distribution builds) take the cell form instead: the host stores the
+// interpolant of cell c as value(x) = s_c * x + a_c (coefficients from f64), the lookup is one 8-byte LDS read and
+// one FMA, and nothing needs verifying -- a guess that lands in the neighbouring cell within float rounding of a
+// node extends that cell's line by <= 1e-3 cell. Error against the exact piecewise-linear interpolant: 3.6e-7 mean
+// / 5.7e-6 max on C4's log-PDF table, the same as the reference's own f32 evaluation (2.7e-7 / 3.4e-6). Half the
+// LDS bytes and bank conflicts of the key/value form, ~10 VALU instead of ~24. Compiled in when the module was
+// built with cell_tables (every PDF / log-PDF table of the call has cells; the host layer decides per call).
+#if MCX_CELL_TABLES
+MCX_DEV float2 mcx_cell_fetch(const McxTable& tb, float x) {
+    const float gf = fminf(fmaxf((x - tb.k0) * tb.inv_dk, 0.0f), (float)(tb.n - 2u));
+    return tb.cells[(u32)gf];
+}
+#endif
+
 MCX_DEV float mcx_table_lookup(const McxTable& tb, float x, float outside) {
     const float2* kv = tb.kv;
     const u32 n = tb.n;
     const bool out_of_range = (x < tb.k0) || (x > tb.k1);
+#if MCX_CELL_TABLES
+    (void)kv;
+    float2 c = mcx_cell_fetch(tb, x);
+#if MCX_LOOKUP_BRANCHLESS
+    // keep the read unconditional: otherwise the compiler sinks it into an exec-masked block per lookup, which
+    // serialises the LDS round trips of a step's lookups behind scalar branches
+    asm volatile("" : "+v"(c.x), "+v"(c.y));
+#endif
+    return out_of_range ? outside : fmaf(c.y, x, c.x);
+#else
     float v;
 #if MCX_UNIFORM_TABLES
     {                                                         // every table of this module is a uniform grid
@@ -279,6 +341,7 @@ MCX_DEV float mcx_table_lookup(const McxTable& tb, float x, float outside) {
     }
 #endif
     return out_of_range ? outside : v;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

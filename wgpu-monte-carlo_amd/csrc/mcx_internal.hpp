@@ -21,4 +21,9 @@ LaunchPlan plan_integrate(const mcx_shard& s, uint32_t target_phys, uint32_t blo
 void analyse_table(int kind, const float* keys, uint32_t n, float* inv_dk, std::vector<uint32_t>* guide,
                    uint32_t* guide_bits);
 
+// PDF / log-PDF tables whose keys are an f32 linspace: per-cell line coefficients {a_c, s_c}, c < n-1, with
+// value(x) = s_c * x + a_c on cell c (the reference's interpolant, distribution.rs:181-223, in slope-intercept form,
+// coefficients computed in f64). Empty when the keys are not such a grid (then the verified / searched path runs).
+void build_cells(const float* keys, const float* values, uint32_t n, std::vector<float>* cells);
+
 }  // namespace mcx

@@ -151,4 +151,27 @@ void analyse_table(int kind, const float* keys, uint32_t n, float* inv_dk, std::
     *guide_bits = bits;
 }
 
+void build_cells(const float* keys, const float* values, uint32_t n, std::vector<float>* cells) {
+    cells->clear();
+    if (n < 2u) return;
+    const double k0 = keys[0], span = (double)keys[n - 1u] - k0;
+    if (!(span > 0.0) || !std::isfinite(span)) return;
+    const double dk = span / (double)(n - 1u);
+    // strict grid: every key within max(1e-3 cell, 1 f32 ulp of the largest key) of k0 + i*dk. The arithmetic cell
+    // guess is not verified on this path, so a merely "nearly uniform" table (analyse_table's 1/4-cell test) is
+    // not enough.
+    const double maxabs = std::fmax(std::fabs(k0), std::fabs((double)keys[n - 1u]));
+    const double tol = std::fmax(1.0e-3 * dk, maxabs * 1.1920929e-7);
+    if (tol > 0.05 * dk) return;                       // cells narrower than f32 can resolve
+    for (uint32_t i = 0; i < n; ++i)
+        if (!(std::fabs((double)keys[i] - (k0 + dk * (double)i)) <= tol) || !std::isfinite((double)values[i])) return;
+    cells->resize(2ull * (n - 1u));
+    for (uint32_t c = 0; c + 1u < n; ++c) {
+        const double x0 = keys[c], x1 = keys[c + 1u], v0 = values[c], v1 = values[c + 1u];
+        const double s = (v1 - v0) / (x1 - x0);
+        (*cells)[2ull * c] = (float)(v0 - s * x0);
+        (*cells)[2ull * c + 1u] = (float)s;
+    }
+}
+
 }  // namespace mcx

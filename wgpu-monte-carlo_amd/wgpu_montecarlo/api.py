@@ -93,12 +93,23 @@ def functions_to_hip(functions: Sequence[FunctionLike], math="default") -> str:
     return "\n\n".join(parts)
 
 
+_PDF_OUTSIDE_SUBSET = set()      # code objects of PDF closures the emitter rejected
+
+
 def _pdf_to_hip(dist: Distribution, name: str, math="default") -> Optional[str]:
     """HIP text of a distribution's PDF closure, or None when it is outside the emitter's subset
     (the reference's table-vs-analytic decision, __init__.py:825-838)."""
+    fn = dist._pdf_func
+    code = getattr(fn, "__code__", None)
+    if code is not None and code in _PDF_OUTSIDE_SUBSET:     # e.g. the np.interp closure of from_pdf_table: decided once
+        return None
     try:
-        return emit_hip.emit_function(frontend.lower(dist._pdf_func), name, math)
+        ir_fn = frontend.lower(fn)
+        key = (code, name, math, tuple(ir_fn.consts.items()))
+        return _emit_cached(key, lambda: emit_hip.emit_function(ir_fn, name, math))
     except TranspilerError:
+        if code is not None:
+            _PDF_OUTSIDE_SUBSET.add(code)
         return None
 
 
@@ -234,6 +245,11 @@ class MonteCarloIntegrator:
                 f"saturates at about 3e-5 absolute. Pass rng='philox' to MonteCarloIntegrator for a 128-bit counter stream.",
                 UserWarning, stacklevel=3)
 
+    def _cell_tables(self, *tables) -> bool:
+        """Compile the one-read-one-FMA lookup when every PDF / log-PDF table of the call is a strict grid."""
+        tables = [t for t in tables if t is not None]
+        return bool(tables) and not self._precise_sampler and all(t.has_cells for t in tables)
+
     def _rank_world(self):
         return (self._group.rank, self._group.world) if self._group is not None else (0, 1)
 
@@ -292,7 +308,8 @@ class MonteCarloIntegrator:
                                  p_table=p_table is not None, q_table=q_table is not None,
                                  guard_endpoints=self._guard, precise_sampler=self._precise_sampler,
                                  tables_lds=lds_ok, rng=self._rng, second_moments=self._std_error,
-                                 unit_params=_unit_params(code, p1, p2))
+                                 unit_params=_unit_params(code, p1, p2),
+                                 cell_tables=self._cell_tables(p_table, q_table))
         mod = self._engine.module(user_src, desc)
         rank, world = self._rank_world()
         values, n_eff = self._run(k * (2 if self._std_error else 1), lambda d_sums, stream: self._engine.integrate(
@@ -341,7 +358,8 @@ class MonteCarloIntegrator:
             walk = runtime.WALK_RANDOM_SYMMETRIC if symmetric else runtime.WALK_RANDOM
         desc = runtime.make_desc(runtime.KIND_MCMC, len(functions), code, guard_endpoints=self._guard,
                                  precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng,
-                                 unit_params=_unit_params(code, p1, p2), second_moments=self._std_error, walk=walk)
+                                 unit_params=_unit_params(code, p1, p2), second_moments=self._std_error, walk=walk,
+                                 cell_tables=self._cell_tables(t_table, q_table))
         mod = self._engine.module(user_src, desc)
         rank, world = self._rank_world()
         k = len(functions)

@@ -46,7 +46,7 @@ class ModuleDesc(C.Structure):
                 ("p_table", C.c_int32), ("q_table", C.c_int32), ("guard_endpoints", C.c_int32),
                 ("precise_sampler", C.c_int32), ("block", C.c_int32), ("tables_lds", C.c_int32),
                 ("rng", C.c_int32), ("unit_params", C.c_int32), ("second_moments", C.c_int32),
-                ("walk", C.c_int32)]
+                ("walk", C.c_int32), ("cell_tables", C.c_int32)]
 
 
 class IntegrateParams(C.Structure):
@@ -69,7 +69,7 @@ EXPORTED_SYMBOLS = [
     "mcx_shard_units", "mcx_shard_chains", "mcx_device_count", "mcx_engine_create", "mcx_engine_destroy", "mcx_engine_device",
     "mcx_engine_last_kernel_ms", "mcx_engine_last_launch", "mcx_engine_set_target_threads", "mcx_module_build",
     "mcx_module_precompile", "mcx_result_rows", "mcx_module_source", "mcx_free", "mcx_module_release", "mcx_cache_dir",
-    "mcx_table_create", "mcx_table_release", "mcx_table_info", "mcx_integrate", "mcx_integrate_device",
+    "mcx_table_create", "mcx_table_release", "mcx_table_info", "mcx_table_has_cells", "mcx_table_cells", "mcx_integrate", "mcx_integrate_device",
     "mcx_mcmc", "mcx_mcmc_device",
 ]
 
@@ -147,6 +147,8 @@ def load():
         L.mcx_table_release.argtypes = [vp]
         L.mcx_table_release.restype = None
         L.mcx_table_info.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(u32)]
+        L.mcx_table_has_cells.argtypes = [vp]
+        L.mcx_table_cells.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), u32, C.POINTER(C.c_float)]
         L.mcx_integrate.argtypes = [vp, vp, C.POINTER(IntegrateParams), C.POINTER(C.c_double), C.POINTER(u64)]
         L.mcx_integrate_device.argtypes = [vp, vp, C.POINTER(IntegrateParams), vp, vp, C.POINTER(u64)]
         L.mcx_mcmc.argtypes = [vp, vp, C.POINTER(McmcParams), C.POINTER(C.c_double), C.POINTER(u64)]
@@ -203,12 +205,25 @@ def shard_chains(total_chains: int, rank: int, world: int):
 def make_desc(kind: int, k: int, dist_type: int, weight: bool = False, p_table: bool = False,
               q_table: bool = False, guard_endpoints: bool = True, precise_sampler: bool = False,
               block: int = 0, tables_lds: bool = True, rng: int = 0, second_moments: bool = False,
-              unit_params: bool = False, walk: int = 0) -> ModuleDesc:
+              unit_params: bool = False, walk: int = 0, cell_tables: bool = False) -> ModuleDesc:
     if not block and os.environ.get("MCX_BLOCK"):        # tuning knob
         block = int(os.environ["MCX_BLOCK"])
     return ModuleDesc(kind, k, dist_type, int(weight), int(p_table), int(q_table), int(guard_endpoints),
                       int(precise_sampler), int(block), int(tables_lds), int(rng), int(unit_params), int(second_moments),
-                      int(walk))
+                      int(walk), int(cell_tables))
+
+
+def table_cells(keys, values):
+    """Per-cell {intercept, slope} of a strict-grid PDF / log-PDF table (float32 [n-1, 2]) or None (include/mcx.h:
+    mcx_table_cells)."""
+    k = np.ascontiguousarray(keys, dtype=np.float32)
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    out = np.zeros((max(len(k) - 1, 0), 2), dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    rc = int(load().mcx_table_cells(k.ctypes.data_as(fp), v.ctypes.data_as(fp), len(k), out.ctypes.data_as(fp)))
+    if rc < 0:
+        check(rc)
+    return out if rc == 1 else None
 
 
 def result_rows(desc: ModuleDesc) -> int:
@@ -266,6 +281,7 @@ class Table:
         check(load().mcx_table_create(engine._h, kind, keys.ctypes.data_as(fp), values.ctypes.data_as(fp),
                                       len(keys), C.byref(self._h)))
         self.kind, self.n = kind, len(keys)
+        self.has_cells = int(load().mcx_table_has_cells(self._h)) == 1     # slope-intercept cell form (strict grid)
 
     def info(self) -> dict:
         n, inv, bits = C.c_uint32(), C.c_float(), C.c_uint32()
