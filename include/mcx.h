@@ -179,6 +179,9 @@ int  mcx_table_info(const mcx_table* t, uint32_t* n, float* inv_dk, uint32_t* gu
  * slope-intercept form, coefficients from f64). Returns 1 and fills cells_out[2 * (n - 1)] = {intercept, slope} per
  * cell (cells_out may be NULL), or 0 when the keys are not such a grid -- lookups then run the verified / searched
  * key-value path. */
+/* LDS bytes a launch stages for this table (key/value pairs or cells, CDF slopes, guide): what a module built with
+ * tables_lds = 1 needs per workgroup for it. */
+uint32_t mcx_table_lds_bytes(const mcx_table* t);
 /* 1 if the table was stored with slope-intercept cells (PDF / log-PDF kinds on a strict f32-linspace grid), else 0. */
 int  mcx_table_has_cells(const mcx_table* t);
 int  mcx_table_cells(const float* keys, const float* values, uint32_t n, float* cells_out);

@@ -24,6 +24,7 @@ typedef struct McxTableDesc {
     float   inv_dk;         // (n-1)/(key[n-1]-key[0]) if the keys form a uniform grid, else 0
     mcx_u32 _pad;
     const float* cells;     // device pointer, n-1 {intercept, slope} pairs (PDF / log-PDF tables on a strict grid), or null
+    const float* slopes;    // device pointer, n inverse-CDF slopes dx/dcdf per cell (CDF tables), or null
 } McxTableDesc;
 
 // K1 / K2: plain and importance-sampling integration.

@@ -191,6 +191,7 @@ struct McxTable {
     const u32* guide;     // CDF only: guide[b] = lo | hi << 16, the search window of bucket b, or null
     u32   guide_bits;     // number of buckets G = 1 << guide_bits
     const float2* cells;  // PDF / log-PDF on a strict grid: cells[c] = {intercept, slope} of cell c, else null (then kv is set)
+    const float* slopes;  // CDF: slopes[c] = dx/dcdf of cell c (0 for cells narrower than 1e-10), or null
 };
 
 // a / b with v_rcp_f32 (<= 1.5 ulp): used for the interpolation weights and the importance ratio.
@@ -251,11 +252,20 @@ MCX_DEV float mcx_sample_cdf(const McxTable& tb, float u) {
         low = mcx_lower_bound_capped<12>(tb.kv, n, u);
     }
     const u32 il = (low > 1u ? low : 1u) - 1u;
+#if !MCX_PRECISE_SAMPLER
+    // x = x[il] + slope[il] * (u - cdf[il]): the same interpolant with the division done once on the host (every CDF
+    // table carries its slopes). low == 0 (u <= cdf[0]) must return x[0]: the difference is clamped at 0 -- an output
+    // modifier of the subtraction, not an instruction.
+    const float2 a = tb.kv[il];
+    const float d = fminf(fmaxf(u - a.x, 0.0f), 1.0f);
+    return fmaf(tb.slopes[il], d, a.y);
+#else
     const u32 ih = low < n - 1u ? low : n - 1u;
     const float2 a = tb.kv[il], b2 = tb.kv[ih];
     const float dc = b2.x - a.x;
     const float t = mcx_div(u - a.x, dc);
     return dc < 1.0e-10f ? a.y : mcx_mix(a.y, b2.y, t);
+#endif
 }
 
 // pdf_*_from_table / log_pdf_*_from_table (distribution.rs:181-223, 375-417). key = x, value = pdf.

@@ -90,6 +90,7 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
     t.guide = nullptr;
     t.kv = nullptr;
     t.cells = nullptr;
+    t.slopes = nullptr;
     t.k0 = 0.0f;
     t.k1 = 0.0f;
     if (d.n == 0u) return t;
@@ -105,6 +106,12 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
     for (u32 i = threadIdx.x; i < count; i += MCX_BLOCK) dst[i] = src[i];
     off += d.n * 8u;
     if (cell_form) t.cells = dst; else t.kv = dst;
+    if (d.slopes != nullptr) {
+        float* sdst = (float*)(mcx_lds_raw + off);
+        for (u32 i = threadIdx.x; i < d.n; i += MCX_BLOCK) sdst[i] = d.slopes[i];
+        off += d.n * 4u;
+        t.slopes = sdst;
+    }
     if (d.guide != nullptr) {
         u32* gdst = (u32*)(mcx_lds_raw + off);
         u32 gn = 1u << d.guide_bits;
@@ -114,6 +121,7 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
     }
 #else
     if (cell_form) t.cells = (const float2*)d.cells; else t.kv = (const float2*)d.kv;
+    t.slopes = d.slopes;
     t.guide = d.guide;
 #endif
     t.k0 = d.kv[0];

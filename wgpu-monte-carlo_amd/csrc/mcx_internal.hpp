@@ -24,6 +24,10 @@ void analyse_table(int kind, const float* keys, uint32_t n, float* inv_dk, std::
 // PDF / log-PDF tables whose keys are an f32 linspace: per-cell line coefficients {a_c, s_c}, c < n-1, with
 // value(x) = s_c * x + a_c on cell c (the reference's interpolant, distribution.rs:181-223, in slope-intercept form,
 // coefficients computed in f64). Empty when the keys are not such a grid (then the verified / searched path runs).
+// CDF tables: slope[c] = (x[c+1] - x[c]) / (cdf[c+1] - cdf[c]) of cell c < n-1 (0 where the reference's lookup
+// returns x[c] because the cell is narrower than 1e-10, distribution.rs:152-155), slope[n-1] = 0.
+void build_cdf_slopes(const float* cdf, const float* x, uint32_t n, std::vector<float>* slopes);
+
 void build_cells(const float* keys, const float* values, uint32_t n, std::vector<float>* cells);
 
 }  // namespace mcx

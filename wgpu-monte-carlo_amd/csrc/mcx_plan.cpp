@@ -151,6 +151,16 @@ void analyse_table(int kind, const float* keys, uint32_t n, float* inv_dk, std::
     *guide_bits = bits;
 }
 
+void build_cdf_slopes(const float* cdf, const float* x, uint32_t n, std::vector<float>* slopes) {
+    slopes->assign(n, 0.0f);
+    for (uint32_t c = 0; c + 1u < n; ++c) {
+        const float dc = cdf[c + 1u] - cdf[c];                     // f32, like the lookup it replaces
+        if (dc < 1.0e-10f || !std::isfinite(dc)) continue;
+        const double s = ((double)x[c + 1u] - (double)x[c]) / (double)dc;
+        (*slopes)[c] = std::isfinite(s) ? (float)s : 0.0f;
+    }
+}
+
 void build_cells(const float* keys, const float* values, uint32_t n, std::vector<float>* cells) {
     cells->clear();
     if (n < 2u) return;

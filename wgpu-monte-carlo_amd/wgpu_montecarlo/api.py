@@ -198,15 +198,7 @@ class MonteCarloIntegrator:
 
     @staticmethod
     def _lds_bytes(*tables: Optional[runtime.Table]) -> int:
-        total = 0
-        for tb in tables:
-            if tb is None:
-                continue
-            total += tb.n * 8
-            bits = tb.info()["guide_bits"]
-            if bits:
-                total += (1 << bits) * 4
-        return total
+        return sum(tb.lds_bytes for tb in tables if tb is not None)
 
     def _run(self, rows: int, call):
         """Run one sharded launch and combine the ranks with ONE sum all-reduce of `rows` doubles.

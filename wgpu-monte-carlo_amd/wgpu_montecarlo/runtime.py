@@ -69,7 +69,7 @@ EXPORTED_SYMBOLS = [
     "mcx_shard_units", "mcx_shard_chains", "mcx_device_count", "mcx_engine_create", "mcx_engine_destroy", "mcx_engine_device",
     "mcx_engine_last_kernel_ms", "mcx_engine_last_launch", "mcx_engine_set_target_threads", "mcx_module_build",
     "mcx_module_precompile", "mcx_result_rows", "mcx_module_source", "mcx_free", "mcx_module_release", "mcx_cache_dir",
-    "mcx_table_create", "mcx_table_release", "mcx_table_info", "mcx_table_has_cells", "mcx_table_cells", "mcx_integrate", "mcx_integrate_device",
+    "mcx_table_create", "mcx_table_release", "mcx_table_info", "mcx_table_lds_bytes", "mcx_table_has_cells", "mcx_table_cells", "mcx_integrate", "mcx_integrate_device",
     "mcx_mcmc", "mcx_mcmc_device",
 ]
 
@@ -148,6 +148,8 @@ def load():
         L.mcx_table_release.restype = None
         L.mcx_table_info.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(u32)]
         L.mcx_table_has_cells.argtypes = [vp]
+        L.mcx_table_lds_bytes.argtypes = [vp]
+        L.mcx_table_lds_bytes.restype = u32
         L.mcx_table_cells.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), u32, C.POINTER(C.c_float)]
         L.mcx_integrate.argtypes = [vp, vp, C.POINTER(IntegrateParams), C.POINTER(C.c_double), C.POINTER(u64)]
         L.mcx_integrate_device.argtypes = [vp, vp, C.POINTER(IntegrateParams), vp, vp, C.POINTER(u64)]
@@ -282,6 +284,7 @@ class Table:
                                       len(keys), C.byref(self._h)))
         self.kind, self.n = kind, len(keys)
         self.has_cells = int(load().mcx_table_has_cells(self._h)) == 1     # slope-intercept cell form (strict grid)
+        self.lds_bytes = int(load().mcx_table_lds_bytes(self._h))          # staged per workgroup when tables_lds = 1
 
     def info(self) -> dict:
         n, inv, bits = C.c_uint32(), C.c_float(), C.c_uint32()
