@@ -224,8 +224,8 @@ def main():
                 "frac": valu_achieved / VALU_PEAK_LANEOPS,
                 # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command
                 # (profiles/r01_bench_n1_pmc_{fetch,write}_counters.csv): WRITE_SIZE 128 KiB (= the algorithmic
-                # n_blocks*K*8 B of partial sums) + FETCH_SIZE 31.5 KiB (code objects + kernel arguments).
-                "traffic": 128 * 1024 + 31.5 * 1024 if world == 1 and launch["n_blocks"] == 4096 else None,
+                # n_blocks*K*8 B of partial sums) + FETCH_SIZE 37.1 KiB (code objects + kernel arguments).
+                "traffic": 128 * 1024 + 37.1 * 1024 if world == 1 and launch["n_blocks"] == 4096 else None,
                 "kernel": "mcx_integrate_kernel",
                 "measured_valu_peak": 51.5,   # Tlane-op/s sustained by v_fma_f32 (profiles/r01_valu_rates_microbench.txt)
                 "kernel_ms": kernel_ms,
@@ -237,7 +237,7 @@ def main():
             # the same kernel against the HBM roofline, in the generic schema: algorithmic bytes = K*8 B per workgroup
             "roofline_hbm": {"bound": "hbm", "achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": hbm_gbps / HBM_PEAK_GBPS,
-                             "traffic": 128 * 1024 + 31.5 * 1024 if world == 1 and launch["n_blocks"] == 4096 else None,
+                             "traffic": 128 * 1024 + 37.1 * 1024 if world == 1 and launch["n_blocks"] == 4096 else None,
                              "algorithmic_bytes_per_launch": hbm_bytes,
                              "note": "the kernel writes one K*8-byte record per workgroup and reads only code + arguments: "
                                      "HBM is ~4e-5 of peak by design, not the bound"},
