@@ -126,7 +126,7 @@ typedef struct mcx_module_desc {
     int32_t tables_lds;        /* 1 (default): tables staged in LDS; 0: read from HBM/L2 */
     int32_t rng;               /* 0 (default): the reference's PCG counter hash (parity stream);
                                 * 1: Philox4x32-10, key (seed, 'MCX1'); counter (idx, i/4, 0, 0) for K1/K2 (four iterations per
-                                * call), (idx, it, 1, 0) for K3 (one call per MH step) -- opt-in for runs that draw more
+                                * call), (idx, it / 2, 1, 0) for K3 (one call per two MH steps) -- opt-in for runs that draw more
                                 * than ~2^32 uniforms */
     int32_t unit_params;       /* 1: the caller guarantees param1/param2 are the identity -- normal(0,1), uniform(0,1),
                                 * exponential(1) -- so the affine map of the sampler is not emitted (bit-identical results) */

@@ -358,7 +358,7 @@ typedef struct {
     const float* target_logpdf;    /* interleaved [n, x0, lp0, ...] */
     const float* proposal_logpdf;  /* interleaved */
     int32_t  guard;
-    int32_t  rng;                  /* 0: reference stream; 1: libmcx's opt-in Philox stream (one call per step) */
+    int32_t  rng;                  /* 0: reference stream; 1: libmcx's opt-in Philox stream (one call per two steps) */
     int32_t  walk;                 /* 0: independent proposals (the reference). libmcx extensions (not in the reference, which
                                     * says "For now, we use independent proposal", shader_gen.rs:514): 1: random walk
                                     * x' = x + d, d ~ q, log alpha = log p(x') + log q(-d) - log p(x) - log q(d);
@@ -367,20 +367,22 @@ typedef struct {
     float    x0;                   /* random walk: chains start at x0 + d_0 */
 } orc_mcmc_args;
 
-/* Philox stream of libmcx for K3: call (idx, it, 1, 0), key (seed, 'MCX1'); outputs (0,1) -> proposal (z0 of the
- * Box-Muller pair, or one uniform from output 0), output 2 -> accept uniform. it = 0 is the initial state. */
+/* Philox stream of libmcx for K3: one call per two steps, (idx, it >> 1, 1, 0), key (seed, 'MCX1'). Step `it` takes
+ * half h = it & 1: normal proposal z0 (h = 0) / z1 (h = 1) of the Box-Muller pair from outputs (0, 1), any other
+ * proposal from output h; accept uniform from output 2 + h. it = 0 is the initial state. */
 static float mcmc_sample_q_philox(const orc_mcmc_args* a, uint32_t idx, uint32_t it, uint32_t* accept_hash) {
-    uint32_t ctr[4] = {idx, it, 1u, 0u}, key[2] = {a->seed, 0x4d435831u}, o[4];
+    uint32_t ctr[4] = {idx, it >> 1, 1u, 0u}, key[2] = {a->seed, 0x4d435831u}, o[4];
+    const uint32_t half = it & 1u;
     orc_philox4x32_10(ctr, key, o);
-    if (accept_hash) *accept_hash = o[2];
+    if (accept_hash) *accept_hash = o[2u + half];
     if (a->proposal_type == ORC_DIST_NORMAL) {
         float u1 = u_from_hash(o[0]);
         if (a->guard && o[0] == 0u) u1 = 0x1.0p-33f;
         float r = sqrtf(-2.0f * logf(u1));
         float theta = 6.283185307179586f * u_from_hash(o[1]);
-        return a->param1 + a->param2 * (r * cosf(theta));
+        return a->param1 + a->param2 * (r * (half ? sinf(theta) : cosf(theta)));
     }
-    float rng = u_from_hash(o[0]);
+    float rng = u_from_hash(o[half]);
     if (a->proposal_type == ORC_DIST_UNIFORM) {
         if (a->guard && rng >= 1.0f) rng = 0x1.fffffep-1f;
         return orc_sample_uniform(rng, a->param1, a->param2);

@@ -427,17 +427,24 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     // ---- initial state ~ proposal, counter iter = 0 (shader_gen.rs:445-463) ----
     float cur_x;
 #if MCX_RNG == 1
-    // Philox stream (opt-in): one call per step, counter (idx, it, 1, 0): outputs (x, y) feed the proposal
-    // (a Box-Muller pair of which z0 is used, or one uniform), output z is the accept uniform. it = 0: initial state.
+    // Philox stream (opt-in): one call per TWO steps, counter (idx, it >> 1, 1, 0). Step `it` takes half it & 1 of
+    // the call: the normal proposal is z0 (even) / z1 (odd) of the Box-Muller pair from outputs (x, y), any other
+    // proposal draws from output x (even) / y (odd); the accept uniform is output z (even) / w (odd). it = 0 is the
+    // initial state (even half of call 0, no accept test).
+    float ph_odd_draw;             // the odd half of call 0, consumed by step 1
+    u32 ph_odd_accept;
     {
         const McxU4 o = mcx_philox4x32_10(McxU4{idx, 0u, 1u, 0u}, a.seed, MCX_PHILOX_KEY1);
 #if MCX_DIST == MCX_DIST_NORMAL
         float z0, z1;
         mcx_box_muller(o.x, o.y, z0, z1);
         cur_x = MCX_AFFINE(z0);
+        ph_odd_draw = MCX_AFFINE(z1);
 #else
         cur_x = mcx_draw_proposal(o.x, a, cdf_tb);
+        ph_odd_draw = mcx_draw_proposal(o.y, a, cdf_tb);
 #endif
+        ph_odd_accept = o.w;
     }
 #elif MCX_DIST == MCX_DIST_NORMAL
     float z_cached;
@@ -525,14 +532,17 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #endif
 
 #if MCX_RNG == 1
-    for (u32 it = 1u; it <= total_steps; ++it) {
-        const McxU4 o = mcx_philox4x32_10(McxU4{idx, it, 1u, 0u}, a.seed, MCX_PHILOX_KEY1);
+    if (total_steps >= 1u) mh_step_h(1u, ph_odd_draw, ph_odd_accept);
+    for (u32 it = 2u; it <= total_steps; it += 2u) {
+        const McxU4 o = mcx_philox4x32_10(McxU4{idx, it >> 1, 1u, 0u}, a.seed, MCX_PHILOX_KEY1);
 #if MCX_DIST == MCX_DIST_NORMAL
         float z0, z1;
         mcx_box_muller(o.x, o.y, z0, z1);
         mh_step_h(it, MCX_AFFINE(z0), o.z);
+        if (it + 1u <= total_steps) mh_step_h(it + 1u, MCX_AFFINE(z1), o.w);      // wave-uniform
 #else
         mh_step_h(it, mcx_draw_proposal(o.x, a, cdf_tb), o.z);
+        if (it + 1u <= total_steps) mh_step_h(it + 1u, mcx_draw_proposal(o.y, a, cdf_tb), o.w);
 #endif
     }
 #elif MCX_DIST == MCX_DIST_NORMAL

@@ -156,7 +156,7 @@ class MonteCarloIntegrator:
             (reference behaviour, can produce log(0)); default False guards the end points.
         rng: "pcg_ref" (default) is the reference's counter hash -- bit-exact sample indexing, but a 32-bit
             counter space that is oversubscribed beyond ~4e9 uniforms per call; "philox" is Philox4x32-10 with a
-            128-bit counter (four iterations per call for integrate / importance sampling, one call per MH step).
+            128-bit counter (four iterations per call for integrate / importance sampling, one call per two MH steps).
         std_error: also accumulate sum (f_k w)^2 in the same pass; integrate / importance-sampling results then
             carry result.meta["std_error"][k] = sqrt((E[(f w)^2] - E[f w]^2) / N_eff) (extension; K <= 32).
             integrate_mcmc results carry batch-means standard errors over the independent chains plus
