@@ -232,16 +232,17 @@ MCX_DEV float mcx_mix(float a, float b, float t) {
 }
 
 // sample_from_cdf_table (distribution.rs:128-158). key = cdf, value = x.
-MCX_DEV float mcx_sample_cdf(const McxTable& tb, float u) {
+// h is the hash u = float(h) * 2^-32 was made from.
+MCX_DEV float mcx_sample_cdf(const McxTable& tb, float u, u32 h) {
     const u32 n = tb.n;
     u32 low;
     if (tb.guide != nullptr) {
         // bucket of u, then a short search inside the bucket's window [lo, hi]: same index as the full
         // lower bound because the table is non-decreasing (checked on the host) and n <= 4096.
-        const u32 G = 1u << tb.guide_bits;
-        u32 b = (u32)(u * (float)G);
-        b = b > G - 1u ? G - 1u : b;
-        const u32 w = tb.guide[b];
+        // The bucket comes from the integer: b = h >> (32 - bits). Rounding h to 24 bits moves u by less than a
+        // bucket boundary (b/G and (b+1)/G are representable), so b/G <= u <= (b+1)/G still holds and the window --
+        // whose upper end is the lower bound of (b+1)/G itself -- still contains the answer.
+        const u32 w = tb.guide[h >> (32u - tb.guide_bits)];
         u32 lo = w & 0xFFFFu, hi = w >> 16;
         while (lo < hi) {
             u32 mid = (lo + hi) >> 1;
@@ -251,7 +252,7 @@ MCX_DEV float mcx_sample_cdf(const McxTable& tb, float u) {
     } else {
         low = mcx_lower_bound_capped<12>(tb.kv, n, u);
     }
-    const u32 il = (low > 1u ? low : 1u) - 1u;
+    const u32 il = __builtin_elementwise_sub_sat(low, 1u);       // max(low, 1) - 1: one saturating subtract
 #if !MCX_PRECISE_SAMPLER
     // x = x[il] + slope[il] * (u - cdf[il]): the same interpolant with the division done once on the host (every CDF
     // table carries its slopes). low == 0 (u <= cdf[0]) must return x[0]: the difference is clamped at 0 -- an output

@@ -183,7 +183,7 @@ MCX_DEV float mcx_draw(u32 h, const McxIntegrateArgs& a, const McxTable& cdf_tb)
     (void)cdf_tb;
     return mcx_sample_exponential(mcx_u01_closed(h), MCX_UNIT_PARAMS ? 1.0f : a.param1);
 #else
-    return mcx_sample_cdf(cdf_tb, mcx_u01_closed(h));
+    return mcx_sample_cdf(cdf_tb, mcx_u01_closed(h), h);
 #endif
 }
 
@@ -396,7 +396,7 @@ MCX_DEV float mcx_draw_proposal(u32 h, const McxMcmcArgs& a, const McxTable& cdf
     (void)cdf_tb;
     return mcx_sample_exponential(mcx_u01_closed(h), MCX_UNIT_PARAMS ? 1.0f : a.param1);
 #else
-    return mcx_sample_cdf(cdf_tb, mcx_u01_closed(h));
+    return mcx_sample_cdf(cdf_tb, mcx_u01_closed(h), h);
 #endif
 }
 
