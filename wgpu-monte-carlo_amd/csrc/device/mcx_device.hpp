@@ -104,8 +104,10 @@ struct McxU4 { u32 x, y, z, w; };
 MCX_DEV McxU4 mcx_philox4x32_10(McxU4 c, u32 k0, u32 k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const u32 hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const u32 hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        // one 32x32 -> 64 multiply per product (v_mad_u64_u32: 5.2 cycles) instead of v_mul_hi + v_mul_lo (2 x 4.9)
+        const u64 p0 = (u64)0xD2511F53u * (u64)c.x;
+        const u64 p1 = (u64)0xCD9E8D57u * (u64)c.z;
+        const u32 hi0 = (u32)(p0 >> 32), lo0 = (u32)p0, hi1 = (u32)(p1 >> 32), lo1 = (u32)p1;
         c = McxU4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
