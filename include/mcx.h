@@ -142,6 +142,11 @@ typedef struct mcx_module_desc {
     int32_t cell_tables;       /* 1: the caller guarantees every PDF / log-PDF table bound to this module has the
                                 * slope-intercept cell form (mcx_table_has_cells); the lookup is then compiled as one
                                 * 8-byte read + one FMA with no search path (checked at launch; not with precise_sampler) */
+    int32_t q_sampler;         /* 1 (importance sampling with a normal sampling distribution only): the proposal density
+                                * is the sampler's own N(param1, param2), so 1/q(x) = param2 * sqrt(2 pi) * exp(z^2 / 2) is formed
+                                * from the standard-normal deviate z the sampler already holds; mcx_pdf_q is not called. Same
+                                * value as the reference's f * p / q with q from the Distribution.normal closure
+                                * (python/wgpu_montecarlo/__init__.py:893-899), without the second exp and the reciprocal. */
 } mcx_module_desc;
 
 #define MCX_RNG_PCG_REF 0

@@ -130,6 +130,28 @@ def test_importance_sampling_analytic(integrator):
     assert np.all(np.abs(res.values - [0, 1, 0, 3]) < [0.01, 0.02, 0.05, 0.2])
 
 
+def test_q_from_the_sampler_deviate_equals_the_emitted_density(integrator):
+    """desc.q_sampler: 1/q from the Box-Muller deviate against q evaluated by the emitted Distribution.normal closure,
+    same stream: the weights agree to float rounding, sample by sample."""
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo import runtime as rt
+    from wgpu_montecarlo.api import _pdf_to_hip, functions_to_hip
+
+    eng = integrator._engine
+    target, proposal = Distribution.normal(0.3, 0.8), Distribution.normal(-0.4, 1.7)
+    src = functions_to_hip(MOMENTS) + "\n\n" + _pdf_to_hip(target, "mcx_pdf_p")
+    with_q = src + "\n\n" + _pdf_to_hip(proposal, "mcx_pdf_q")
+    plain = eng.module(with_q, rt.make_desc(rt.KIND_INTEGRATE, 4, rt.DIST_NORMAL, weight=True))
+    fused = eng.module(src, rt.make_desc(rt.KIND_INTEGRATE, 4, rt.DIST_NORMAL, weight=True, q_sampler=True))
+    a, n_eff = eng.integrate(plain, 3_000_000, 9, -0.4, 1.7)
+    b, _ = eng.integrate(fused, 3_000_000, 9, -0.4, 1.7)
+    assert np.allclose(a, b, rtol=2e-6, atol=2e-6 * n_eff * 1e-3), (a, b)
+    m = b / n_eff
+    assert abs(m[0] - 0.3) < 0.01 and abs(m[1] - (0.64 + 0.09)) < 0.02
+    with pytest.raises(ValueError, match="q_sampler"):
+        rt.module_source("", rt.make_desc(rt.KIND_INTEGRATE, 1, rt.DIST_UNIFORM, weight=True, q_sampler=True))
+
+
 def test_importance_sampling_target_table(integrator):
     """K2 with a 512-point target PDF table (BASELINE config 3 shape, reference tests/test_importance_sampling.py:335-346)."""
     from wgpu_montecarlo import Distribution

@@ -36,8 +36,8 @@ def build(which, fast):
     if which == "c2":
         return functions_to_hip([f1, f2, f3, f4], fast), rt.make_desc(rt.KIND_INTEGRATE, 4, rt.DIST_NORMAL, unit_params=True)
     if which == "c3":
-        src = functions_to_hip([f1, f2, f3, f4], fast) + "\n" + _pdf_to_hip(Distribution.normal(2.0, 3.0), "mcx_pdf_q", fast)
-        return src, rt.make_desc(rt.KIND_INTEGRATE, 4, rt.DIST_NORMAL, weight=True, p_table=True, cell_tables=True)
+        return functions_to_hip([f1, f2, f3, f4], fast), rt.make_desc(rt.KIND_INTEGRATE, 4, rt.DIST_NORMAL, weight=True,
+                                                                      p_table=True, cell_tables=True, q_sampler=True)
     if which == "c4":
         return functions_to_hip([f1, f2], fast), rt.make_desc(rt.KIND_MCMC, 2, rt.DIST_NORMAL, cell_tables=True)
     if which == "c5":

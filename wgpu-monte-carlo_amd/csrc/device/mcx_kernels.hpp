@@ -153,6 +153,9 @@ MCX_DEV void mcx_block_reduce_store(double (&v)[N], double* partials) {
 // K1 / K2: fused sample + (weight) + K evaluations + reduction
 // =============================================================================================
 struct McxIsTables { McxTable p, q; };
+#ifndef MCX_Q_SAMPLER
+#define MCX_Q_SAMPLER 0
+#endif
 
 // acc[k * S] is the accumulator of function k (S = 2: the A/B sample lanes are interleaved, see below).
 template <int S>
@@ -165,12 +168,38 @@ MCX_DEV void mcx_accumulate(float x, const McxIsTables& tb, float* acc) {
 #endif
 #if MCX_Q_TABLE
     float q = mcx_table_lookup(tb.q, x, 0.0f);
+#elif MCX_Q_SAMPLER
+    float q = 1.0f;                       // not reached: normal samples go through mcx_accumulate_z
 #else
     float q = mcx_b2f(mcx_pdf_q(x));
 #endif
     mcx_eval_all<S>(x, mcx_div(p, q), acc);
 #else
     mcx_eval_all<S>(x, 1.0f, acc);
+#endif
+}
+
+// Normal sampler: the sample is x = mean + std * z. With MCX_Q_SAMPLER the importance weight uses
+// 1/q(x) = std * sqrt(2 pi) * exp(z^2 / 2) from the deviate itself -- one v_exp_f32 and three multiplies instead of
+// evaluating the emitted N(mean, std) density at x (subtract, divide, square, exp, scale) and taking its reciprocal.
+#ifndef MCX_Q_SAMPLER
+#define MCX_Q_SAMPLER 0
+#endif
+template <int S, class Args>
+MCX_DEV void mcx_accumulate_z(float z, const Args& a, const McxIsTables& tb, float* acc) {
+    const float x = MCX_AFFINE(z);
+#if MCX_WEIGHT && MCX_Q_SAMPLER
+#if MCX_P_TABLE
+    const float p = mcx_table_lookup(tb.p, x, 0.0f);
+#else
+    const float p = mcx_b2f(mcx_pdf_p(x));
+#endif
+    const float sigma = MCX_UNIT_PARAMS ? 1.0f : a.param2;
+    const float inv_q = (sigma * 2.5066282746310002f) * __builtin_amdgcn_exp2f((z * z) * 0.72134752044448170f);
+    mcx_eval_all<S>(x, p * inv_q, acc);
+#else
+    (void)a;
+    mcx_accumulate<S>(x, tb, acc);
 #endif
 }
 
@@ -256,8 +285,8 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 #if MCX_DIST == MCX_DIST_NORMAL
         float z0, z1;
         mcx_box_muller(h_first, h_second, z0, z1);
-        mcx_accumulate<MCX_ACC_S>(MCX_AFFINE(z0), is_tb, acc);
-        if (n_valid > 1u) mcx_accumulate<MCX_ACC_S>(MCX_AFFINE(z1), is_tb, acc + (MCX_ACC_S - 1));
+        mcx_accumulate_z<MCX_ACC_S>(z0, a, is_tb, acc);
+        if (n_valid > 1u) mcx_accumulate_z<MCX_ACC_S>(z1, a, is_tb, acc + (MCX_ACC_S - 1));
 #else
         mcx_accumulate<MCX_ACC_S>(mcx_draw(h_first, a, cdf_tb), is_tb, acc);
         if (n_valid > 1u) mcx_accumulate<MCX_ACC_S>(mcx_draw(h_second, a, cdf_tb), is_tb, acc + (MCX_ACC_S - 1));
@@ -302,8 +331,8 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
             st += 4u * MCX_STATE_STEP;
             float z0, z1;
             mcx_box_muller(h1, h2, z0, z1);
-            mcx_accumulate<MCX_ACC_S>(MCX_AFFINE(z0), is_tb, acc);
-            mcx_accumulate<MCX_ACC_S>(MCX_AFFINE(z1), is_tb, acc + (MCX_ACC_S - 1));
+            mcx_accumulate_z<MCX_ACC_S>(z0, a, is_tb, acc);
+            mcx_accumulate_z<MCX_ACC_S>(z1, a, is_tb, acc + (MCX_ACC_S - 1));
         }
         MCX_FLUSH_ACC();
     }
@@ -315,7 +344,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         float z0, z1;
         mcx_box_muller(h1, h2, z0, z1);
         MCX_ZERO_ACC();
-        mcx_accumulate<MCX_ACC_S>(MCX_AFFINE(z0), is_tb, acc);
+        mcx_accumulate_z<MCX_ACC_S>(z0, a, is_tb, acc);
         MCX_FLUSH_ACC();
     }
 #else

@@ -134,6 +134,22 @@ def _dist_params(dist: Distribution):
     return code, 0.0, 0.0
 
 
+_NORMAL_PDF_CODE = Distribution.normal(0.0, 1.0)._pdf_func.__code__
+
+
+def _is_factory_normal(dist: Distribution, mean: float, std: float) -> bool:
+    """True when dist._pdf_func is the closure Distribution.normal builds for exactly (mean, std) -- i.e. the density
+    exp(-((x - mean)/std)^2 / 2) / (std sqrt(2 pi)) of the distribution the sampler draws from."""
+    fn = dist._pdf_func
+    if getattr(fn, "__code__", None) is not _NORMAL_PDF_CODE or not fn.__closure__:
+        return False
+    try:
+        cells = dict(zip(fn.__code__.co_freevars, (c.cell_contents for c in fn.__closure__)))
+        return float(cells["mean"]) == mean and float(cells["sigma"]) == std and std > 0.0
+    except (KeyError, TypeError, ValueError):
+        return False
+
+
 def _unit_params(code: int, p1: float, p2: float) -> bool:
     """normal(0,1) / uniform(0,1) / exponential(1): the sampler's affine map is the identity and is specialised away."""
     if code == runtime.DIST_NORMAL or code == runtime.DIST_UNIFORM:
@@ -284,6 +300,10 @@ class MonteCarloIntegrator:
         code, p1, p2 = _dist_params(proposal_distribution)
         cdf = self._cdf_table(proposal_distribution)
         p_table = q_table = None
+        # the samples are drawn from the proposal: for Distribution.normal its density is a function of the deviate the
+        # sampler already holds, so the kernel forms 1/q from z instead of evaluating the emitted closure at x
+        q_sampler = (q_src is not None and not self._precise_sampler and code == runtime.DIST_NORMAL
+                     and _is_factory_normal(proposal_distribution, p1, p2))
         if p_src is None:
             xs, dens = target_distribution.get_or_compute_pdf_table()
             p_table = self._table(runtime.TABLE_PDF, xs, dens)
@@ -292,7 +312,7 @@ class MonteCarloIntegrator:
         if q_src is None:
             xs, dens = proposal_distribution.get_or_compute_pdf_table()
             q_table = self._table(runtime.TABLE_PDF, xs, dens)
-        else:
+        elif not q_sampler:
             user_src += "\n\n" + q_src
         lds_ok = self._lds_bytes(cdf, p_table, q_table) <= _LDS_TABLE_BUDGET
         k = len(functions)
@@ -301,7 +321,7 @@ class MonteCarloIntegrator:
                                  guard_endpoints=self._guard, precise_sampler=self._precise_sampler,
                                  tables_lds=lds_ok, rng=self._rng, second_moments=self._std_error,
                                  unit_params=_unit_params(code, p1, p2),
-                                 cell_tables=self._cell_tables(p_table, q_table))
+                                 cell_tables=self._cell_tables(p_table, q_table), q_sampler=q_sampler)
         mod = self._engine.module(user_src, desc)
         rank, world = self._rank_world()
         values, n_eff = self._run(k * (2 if self._std_error else 1), lambda d_sums, stream: self._engine.integrate(
