@@ -142,11 +142,14 @@ typedef struct mcx_module_desc {
     int32_t cell_tables;       /* 1: the caller guarantees every PDF / log-PDF table bound to this module has the
                                 * slope-intercept cell form (mcx_table_has_cells); the lookup is then compiled as one
                                 * 8-byte read + one FMA with no search path (checked at launch; not with precise_sampler) */
-    int32_t q_sampler;         /* 1 (importance sampling with a normal sampling distribution only): the proposal density
-                                * is the sampler's own N(param1, param2), so 1/q(x) = param2 * sqrt(2 pi) * exp(z^2 / 2) is formed
-                                * from the standard-normal deviate z the sampler already holds; mcx_pdf_q is not called. Same
+    int32_t q_sampler;         /* 1 (normal sampling / proposal distribution only): the proposal density is the sampler's own
+                                * N(param1, param2) and is formed from the standard-normal deviate z the sampler already holds.
+                                * Importance sampling: 1/q(x) = param2 * sqrt(2 pi) * exp(z^2 / 2); mcx_pdf_q is not called. Same
                                 * value as the reference's f * p / q with q from the Distribution.normal closure
-                                * (python/wgpu_montecarlo/__init__.py:893-899), without the second exp and the reciprocal. */
+                                * (python/wgpu_montecarlo/__init__.py:893-899), without the second exp and the reciprocal.
+                                * MCMC: log q = -z^2 / 2 (+ a constant that cancels); no proposal_logpdf table is bound. The
+                                * reference interpolates a 2048-point table of that function (src/shader_gen.rs:521-526):
+                                * <= 6e-6 below it inside +-7 std, -100 outside (probability 2.6e-12 per draw). */
 } mcx_module_desc;
 
 #define MCX_RNG_PCG_REF 0
@@ -229,7 +232,7 @@ typedef struct mcx_mcmc_params {
     uint32_t rank, world;
     const mcx_table* cdf;              /* custom proposal */
     const mcx_table* target_logpdf;    /* MCX_TABLE_LOGPDF, required */
-    const mcx_table* proposal_logpdf;  /* MCX_TABLE_LOGPDF, required */
+    const mcx_table* proposal_logpdf;  /* MCX_TABLE_LOGPDF, required unless desc.q_sampler */
     float    x0;                 /* random-walk modules: chains start at x0 + d_0 (d_0 = the iter-0 draw); else ignored */
     uint32_t reserved;           /* 0 */
 } mcx_mcmc_params;

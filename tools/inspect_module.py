@@ -39,7 +39,7 @@ def build(which, fast):
         return functions_to_hip([f1, f2, f3, f4], fast), rt.make_desc(rt.KIND_INTEGRATE, 4, rt.DIST_NORMAL, weight=True,
                                                                       p_table=True, cell_tables=True, q_sampler=True)
     if which == "c4":
-        return functions_to_hip([f1, f2], fast), rt.make_desc(rt.KIND_MCMC, 2, rt.DIST_NORMAL, cell_tables=True)
+        return functions_to_hip([f1, f2], fast), rt.make_desc(rt.KIND_MCMC, 2, rt.DIST_NORMAL, cell_tables=True, q_sampler=True)
     if which == "c5":
         return functions_to_hip(k32(), fast), rt.make_desc(rt.KIND_INTEGRATE, 32, rt.DIST_CUSTOM)
     raise SystemExit("unknown module " + which)

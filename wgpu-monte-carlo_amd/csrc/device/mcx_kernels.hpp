@@ -455,6 +455,8 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 
     // ---- initial state ~ proposal, counter iter = 0 (shader_gen.rs:445-463) ----
     float cur_x;
+    float z_init = 0.0f;          // normal proposal: the standard deviate behind cur_x (MCX_Q_SAMPLER)
+    (void)z_init;
 #if MCX_RNG == 1
     // Philox stream (opt-in): one call per TWO steps, counter (idx, it >> 1, 1, 0). Step `it` takes half it & 1 of
     // the call: the normal proposal is z0 (even) / z1 (odd) of the Box-Muller pair from outputs (x, y), any other
@@ -468,7 +470,8 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
         float z0, z1;
         mcx_box_muller(o.x, o.y, z0, z1);
         cur_x = MCX_AFFINE(z0);
-        ph_odd_draw = MCX_AFFINE(z1);
+        z_init = z0;
+        ph_odd_draw = z1;          // normal: the deviate; mh_step_h applies the affine map
 #else
         cur_x = mcx_draw_proposal(o.x, a, cdf_tb);
         ph_odd_draw = mcx_draw_proposal(o.y, a, cdf_tb);
@@ -482,6 +485,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
         float z0;
         mcx_box_muller(mcx_pcg_out(s0), mcx_pcg_angle(s0 + MCX_STATE_STEP), z0, z_cached);
         cur_x = MCX_AFFINE(z0);       // z1 stays cached for step it = 1
+        z_init = z0;
     }
     // proposal state for even `it`: counters 2*(it+OFFSET), 2*(it+OFFSET)+1
     u32 st_prop = mcx_state(a.seed, idx, 2u * (2u + MCX_PROP_ITER_OFFSET));
@@ -494,7 +498,14 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #endif
     float cur_lp = mcx_table_lookup(lp_tb, cur_x, -100.0f);
 #if MCX_WALK == 0
+#if MCX_Q_SAMPLER
+    // normal proposal: log q(x) = -z^2/2 - log(std sqrt(2 pi)) for the deviate z behind x; the constant cancels in
+    // log alpha. (The reference interpolates a 2048-point table of the same function: up to 6e-6 below it, and -100
+    // beyond 7 std, which a draw reaches with probability 2.6e-12.)
+    float cur_lq = -0.5f * z_init * z_init;
+#else
     float cur_lq = mcx_table_lookup(lq_tb, cur_x, -100.0f);   // pure function of cur_x: cached
+#endif
 #endif
 #if MCX_RNG == 0
     u32 st_acc = mcx_state(a.seed + MCX_ACCEPT_SEED_OFFSET, idx, 1u);
@@ -533,18 +544,34 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
         }
     };
     // One Metropolis-Hastings step with the proposal draw and accept hash ha (shader_gen.rs:511-537).
-    auto mh_step_h = [&](u32 it, float draw, u32 ha) {
+    // `zd`: the standard normal deviate for a normal proposal (the affine map is applied here), else the draw itself.
+    auto mh_step_h = [&](u32 it, float zd, u32 ha) {
+#if MCX_DIST == MCX_DIST_NORMAL
+        const float draw = MCX_AFFINE(zd);
+#else
+        const float draw = zd;
+#endif
 #if MCX_WALK == 0
         const float prop_x = draw;
         float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
+#if MCX_Q_SAMPLER
+        float prop_lq = -0.5f * zd * zd;
+#else
         float prop_lq = mcx_table_lookup(lq_tb, prop_x, -100.0f);
+#endif
         mh_finish(it, prop_x, prop_lp, prop_lq, prop_lp + cur_lq - cur_lp - prop_lq, ha);   // shader_gen.rs:526
 #elif MCX_WALK == 1
         const float prop_x = cur_x + draw;
         float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
+#if MCX_Q_SAMPLER
+        // d = m + s z: log q(-d) - log q(d) = (z^2 - (z + 2m/s)^2) / 2 = -(2m/s) (z + m/s)
+        const float ms = MCX_UNIT_PARAMS ? 0.0f : a.param1 / a.param2;              // wave-uniform
+        mh_finish(it, prop_x, prop_lp, 0.0f, prop_lp - cur_lp - (2.0f * ms) * (zd + ms), ha);
+#else
         float lq_fwd = mcx_table_lookup(lq_tb, draw, -100.0f);                     // q(x' | x) = q(d)
         float lq_back = mcx_table_lookup(lq_tb, -draw, -100.0f);                   // q(x | x') = q(-d)
         mh_finish(it, prop_x, prop_lp, 0.0f, prop_lp + lq_back - cur_lp - lq_fwd, ha);
+#endif
 #else
         const float prop_x = cur_x + draw;
         float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
@@ -567,8 +594,8 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #if MCX_DIST == MCX_DIST_NORMAL
         float z0, z1;
         mcx_box_muller(o.x, o.y, z0, z1);
-        mh_step_h(it, MCX_AFFINE(z0), o.z);
-        if (it + 1u <= total_steps) mh_step_h(it + 1u, MCX_AFFINE(z1), o.w);      // wave-uniform
+        mh_step_h(it, z0, o.z);
+        if (it + 1u <= total_steps) mh_step_h(it + 1u, z1, o.w);      // wave-uniform
 #else
         mh_step_h(it, mcx_draw_proposal(o.x, a, cdf_tb), o.z);
         if (it + 1u <= total_steps) mh_step_h(it + 1u, mcx_draw_proposal(o.y, a, cdf_tb), o.w);
@@ -578,20 +605,20 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     // odd `it` consumes the z1 cached by the previous draw (it = 1: the initial draw's), even `it` draws a
     // new pair from counters 2*(it+OFFSET), +1 (distribution.rs:90-114 through shader_gen.rs:481)
     u32 it = 1u;
-    if (total_steps >= 1u) { mh_step(1u, MCX_AFFINE(z_cached)); it = 2u; }
+    if (total_steps >= 1u) { mh_step(1u, z_cached); it = 2u; }
     for (; it + 1u <= total_steps; it += 2u) {
         float z0, z1;
         mcx_box_muller(mcx_pcg_out(st_prop), mcx_pcg_angle(st_prop + MCX_STATE_STEP), z0, z1);
         st_prop += 4u * MCX_STATE_STEP;
         // (issuing the four table reads of the trip ahead of the first accept test was measured on C4: 13.76 ms
         // against 13.4 ms for this form -- with 8 waves per SIMD the LDS latency is already hidden)
-        mh_step(it, MCX_AFFINE(z0));
-        mh_step(it + 1u, MCX_AFFINE(z1));
+        mh_step(it, z0);
+        mh_step(it + 1u, z1);
     }
     if (it <= total_steps && it >= 2u) {
         float z0, z1;
         mcx_box_muller(mcx_pcg_out(st_prop), mcx_pcg_angle(st_prop + MCX_STATE_STEP), z0, z1);
-        mh_step(it, MCX_AFFINE(z0));
+        mh_step(it, z0);
     }
 #else
     for (u32 it = 1u; it <= total_steps; ++it) {
