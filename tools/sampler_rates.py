@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Kernel throughput of integrate(K=4 moments) for every sampler family at n = 2e9 (GPU box)."""
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "wgpu-monte-carlo_amd"))
+from wgpu_montecarlo import Distribution, MonteCarloIntegrator  # noqa: E402
+
+f1 = lambda x: x
+f2 = lambda x: x**2
+f3 = lambda x: x**3
+f4 = lambda x: x**4
+
+
+def laplace(x):
+    import math
+
+    return math.exp(-abs(x)) / 2
+
+
+def main():
+    n = int(2e9)
+    cases = [("uniform(0,1)", Distribution.uniform(0.0, 1.0)), ("uniform(-2,3)", Distribution.uniform(-2.0, 3.0)),
+             ("normal(0,1)", Distribution.normal(0.0, 1.0)), ("normal(1,2)", Distribution.normal(1.0, 2.0)),
+             ("exponential(1)", Distribution.exponential(1.0)), ("exponential(2.5)", Distribution.exponential(2.5)),
+             ("beta(2,5) [2048-pt CDF]", Distribution.beta(2.0, 5.0)), ("from_pdf exp(-|x|)/2 [CDF table]", Distribution.from_pdf(laplace, support=(-12.0, 12.0)))]
+    for rng in ("pcg_ref", "philox"):
+        mc = MonteCarloIntegrator(rng=rng)
+        for name, dist in cases:
+            best, res = None, None
+            for _ in range(4):
+                res = mc.integrate([f1, f2, f3, f4], dist, n_samples=n)
+                k = res.meta["kernel_ms"]
+                best = k if best is None else min(best, k)
+            print(json.dumps(dict(rng=rng, sampler=name, kernel_ms=round(best, 3), samples_per_s=float("%.3g" % (res.meta["n_eff"] / (best * 1e-3))),
+                                  block=res.meta["block"], lds_bytes=res.meta["lds_bytes"], values=[round(float(v), 5) for v in res.values])), flush=True)
+
+
+if __name__ == "__main__":
+    main()
