@@ -511,6 +511,9 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     u32 st_acc = mcx_state(a.seed + MCX_ACCEPT_SEED_OFFSET, idx, 1u);
 #endif
 
+#if MCX_WALK == 1 && MCX_Q_SAMPLER
+    const float rw_ms = MCX_UNIT_PARAMS ? 0.0f : a.param1 / a.param2;              // mean / std of the increments
+#endif
     // Second half of a Metropolis-Hastings step (shader_gen.rs:527-537): accept test, state update, accumulation.
     // `it` is wave-uniform. prop_lq is used by the independent sampler only (it becomes the cached log q(current)).
     auto mh_finish = [&](u32 it, float prop_x, float prop_lp, float prop_lq, float log_alpha, u32 ha) {
@@ -565,8 +568,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
         float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
 #if MCX_Q_SAMPLER
         // d = m + s z: log q(-d) - log q(d) = (z^2 - (z + 2m/s)^2) / 2 = -(2m/s) (z + m/s)
-        const float ms = MCX_UNIT_PARAMS ? 0.0f : a.param1 / a.param2;              // wave-uniform
-        mh_finish(it, prop_x, prop_lp, 0.0f, prop_lp - cur_lp - (2.0f * ms) * (zd + ms), ha);
+        mh_finish(it, prop_x, prop_lp, 0.0f, prop_lp - cur_lp - (2.0f * rw_ms) * (zd + rw_ms), ha);
 #else
         float lq_fwd = mcx_table_lookup(lq_tb, draw, -100.0f);                     // q(x' | x) = q(d)
         float lq_back = mcx_table_lookup(lq_tb, -draw, -100.0f);                   // q(x | x') = q(-d)
