@@ -114,3 +114,84 @@ def test_many_fused_functions(integrator):
         return m
 
     assert np.all(np.abs(r.values - [beta_moment(k) for k in range(1, 21)]) < 0.01)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_geometry_importance_sampling(case):
+    """K2 on random small geometries: every way the weight can be formed -- target analytic or from a table (strict
+    grid -> cells, perturbed grid -> verified guess), proposal normal (1/q from the deviate), uniform (emitted
+    closure) or custom (CDF sampling + PDF table) -- against the oracle's f * p / q on the same samples."""
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo.api import MonteCarloIntegrator
+
+    rng = np.random.default_rng(9000 + case)
+    target_threads = int(rng.choice([256, 700, 4096, 65536]))
+    n = int(rng.choice([3, 255, 1001, 99_999, 300_001, 700_001]))
+    seed = int(rng.integers(0, 2**32))
+    s2pi = float(np.float32(np.sqrt(2 * np.pi)))
+    # target
+    t_kind = int(rng.integers(0, 3))
+    if t_kind == 0:
+        target, p_spec = Distribution.normal(0.2, 0.7), (oracle.PDF_NORMAL, 0.2, 0.7, s2pi)
+    else:
+        xt = np.linspace(-3.0, 3.5, int(rng.choice([300, 512, 1000])))
+        if t_kind == 2:
+            xt[1:-1] += rng.uniform(-0.2, 0.2, len(xt) - 2) * (xt[1] - xt[0])
+        target = Distribution.from_pdf_table(xt, np.exp(-0.5 * ((xt - 0.2) / 0.7) ** 2))
+        p_spec = (oracle.PDF_TABLE, target._x_table, target._pdf_table)
+    # proposal
+    q_kind = int(rng.integers(0, 3))
+    kw = {}
+    if q_kind == 0:
+        proposal, code, p1, p2 = Distribution.normal(0.0, 1.5), oracle.NORMAL, 0.0, 1.5
+        q_spec = (oracle.PDF_NORMAL, 0.0, 1.5, s2pi)
+    elif q_kind == 1:
+        proposal, code, p1, p2 = Distribution.uniform(-4.0, 4.5), oracle.UNIFORM, -4.0, 4.5
+        q_spec = (oracle.PDF_UNIFORM, -4.0, 4.5, 8.5)
+    else:
+        proposal = Distribution.from_pdf(lambda x: math.exp(-abs(x)) / 2, support=(-9, 9), table_size=int(rng.choice([1200, 2048])))
+        code, p1, p2 = oracle.CUSTOM, 0.0, 0.0
+        q_spec = (oracle.PDF_TABLE, *proposal.get_or_compute_pdf_table())
+        kw = dict(cdf_table=proposal._cdf_table, x_table=proposal._x_table)
+    mc = MonteCarloIntegrator(target_threads=target_threads)
+    res = mc.integrate_importance_sampling(F, target, proposal, n_samples=n, seed=seed)
+    fns = [(oracle.FN_IDENTITY, 0), (oracle.FN_SQ, 0), (oracle.FN_COS, 0)]
+    ref = oracle.integrate(fns, code, p1, p2, n_samples=n, seed=seed, target_threads=target_threads, guard=1,
+                           p=p_spec, q=q_spec, **kw)
+    assert res.meta["n_eff"] == ref["n_eff"]
+    want = ref["sums"] / ref["n_eff"]
+    scale = max(1.0, float(np.max(np.abs(want))))
+    assert np.allclose(res.values, want, rtol=5e-5, atol=5e-5 * scale), (case, t_kind, q_kind, n, res.values, want)
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_random_geometry_mcmc_extensions(case):
+    """Random-walk proposals, the Philox stream and the batch-means rows on random small geometries."""
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo.api import MonteCarloIntegrator
+
+    rng = np.random.default_rng(7000 + case)
+    n_chains = int(rng.choice([1, 256, 257, 1000]))
+    n_steps = int(rng.choice([1, 2, 7, 100, 513]))
+    n_burnin = int(rng.choice([0, 1, 3, 50]))
+    seed = int(rng.integers(0, 2**32))
+    philox = bool(rng.integers(0, 2))
+    kind = int(rng.integers(0, 3))
+    x0 = float(rng.choice([0.0, 0.5, -1.0]))
+    target = Distribution.normal(0.5, 1.0)
+    step, code, p1, p2, walk = [(Distribution.normal(0.0, 1.2), oracle.NORMAL, 0.0, 1.2, 2),
+                                (Distribution.normal(0.4, 1.2), oracle.NORMAL, 0.4, 1.2, 1),
+                                (Distribution.uniform(-1.5, 2.0), oracle.UNIFORM, -1.5, 2.0, 1)][kind]
+    mc = MonteCarloIntegrator(rng="philox" if philox else "pcg_ref", std_error=True)
+    res = mc.integrate_mcmc(F[:2], target, step, n_steps=n_steps, n_chains=n_chains, n_burnin=n_burnin, seed=seed,
+                            proposal_kind="random_walk", initial_state=x0)
+    tx, tl = target.get_log_pdf_table()
+    px, pl = step.get_log_pdf_table()
+    ref = oracle.mcmc([(oracle.FN_IDENTITY, 0), (oracle.FN_SQ, 0)], code, p1, p2, tx, tl, px, pl, n_steps=n_steps,
+                      n_chains=n_chains, n_burnin=n_burnin, seed=seed, guard=1, walk=walk, x0=x0, rng=int(philox))
+    assert res.meta["n_eff"] == ref["n_eff"]
+    want = ref["sums"][:2] / ref["n_eff"]
+    assert np.allclose(res.values, want, rtol=4e-3, atol=4e-3), (case, kind, philox, res.values, want)
+    total_steps = (ref["n_eff"] // n_steps) * (n_steps + n_burnin)
+    assert abs(res.meta["accept_rate"] - ref["sums"][2] / total_steps) < 3e-3
+    assert np.all(np.isfinite(res.meta["std_error"]))
