@@ -421,7 +421,7 @@ def test_philox_shards_and_full_size():
     assert np.all(np.abs(res.values - [0, 1, 0, 3]) < 3.5 * sigma), res.values
 
 
-@pytest.mark.parametrize("n_prop,n_tgt,in_lds", [(5800, 5000, True), (9000, 7000, False)])
+@pytest.mark.parametrize("n_prop,n_tgt,in_lds", [(5800, 5000, True), (1001, 777, True), (9000, 7000, False)])
 def test_large_tables_and_capped_search(integrator, n_prop, n_tgt, in_lds):
     """Tables up to 156 KiB are staged in LDS (one 1024-thread workgroup per CU); beyond that they are read from
     HBM/L2 (tables_lds = 0). With n > 4096 points the reference's 12-step CDF search is NOT an exact lower bound
@@ -433,7 +433,8 @@ def test_large_tables_and_capped_search(integrator, n_prop, n_tgt, in_lds):
     target = Distribution.from_pdf_table(xt, np.exp(-0.5 * xt * xt) / np.sqrt(2 * np.pi))
     res = integrator.integrate_importance_sampling([lambda x: x, lambda x: x**2], target, proposal, n_samples=1_000_000, seed=4)
     # CDF table {cdf, x} + its slopes, proposal PDF table, target PDF table (no guide: n > 4096)
-    assert res.meta["lds_bytes"] == ((2 * n_prop + n_tgt) * 8 + n_prop * 4 if in_lds else 0)
+    guide = 0 if n_prop > 4096 else 4 * 4 * (1 << (n_prop - 1).bit_length())          # G = 4 * pow2ceil(n) entries
+    assert res.meta["lds_bytes"] == ((2 * n_prop + n_tgt) * 8 + (n_prop * 4 + 7) // 8 * 8 + guide if in_lds else 0)
     ref = oracle.integrate([(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2)], oracle.CUSTOM, n_samples=1_000_000, seed=4, guard=1,
                            cdf_table=proposal._cdf_table, x_table=proposal._x_table,
                            p=(oracle.PDF_TABLE, target._x_table, target._pdf_table),

@@ -109,7 +109,7 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
     if (d.slopes != nullptr) {
         float* sdst = (float*)(mcx_lds_raw + off);
         for (u32 i = threadIdx.x; i < d.n; i += MCX_BLOCK) sdst[i] = d.slopes[i];
-        off += d.n * 4u;
+        off += (d.n * 4u + 7u) & ~7u;      // keep the next table's float2 8-byte aligned (same rounding on the host)
         t.slopes = sdst;
     }
     if (d.guide != nullptr) {

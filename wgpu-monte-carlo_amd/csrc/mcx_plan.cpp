@@ -173,6 +173,7 @@ void build_cells(const float* keys, const float* values, uint32_t n, std::vector
     const double maxabs = std::fmax(std::fabs(k0), std::fabs((double)keys[n - 1u]));
     const double tol = std::fmax(1.0e-3 * dk, maxabs * 1.1920929e-7);
     if (tol > 0.05 * dk) return;                       // cells narrower than f32 can resolve
+    if (dk < 2.0e-10) return;                          // the reference's flat-segment guard (dx < 1e-10 -> left value) could fire
     for (uint32_t i = 0; i < n; ++i)
         if (!(std::fabs((double)keys[i] - (k0 + dk * (double)i)) <= tol) || !std::isfinite((double)values[i])) return;
     cells->resize(2ull * (n - 1u));
