@@ -246,6 +246,19 @@ int mcx_mcmc(mcx_engine* e, mcx_module* m, const mcx_mcmc_params* p,
 int mcx_mcmc_device(mcx_engine* e, mcx_module* m, const mcx_mcmc_params* p,
                     void* d_sums, void* stream, uint64_t* n_eff_out);
 
+/* ------------------------------------------------------------------------------------------
+ * One host thread, several devices (no torch, no RCCL): the shards params[r] (rank = r, world = n) are enqueued on
+ * engines[r] without waiting, then the n results of mcx_result_rows doubles each are read back and added on the
+ * host in rank order. The reference is single-device (src/engine.rs:91-131); this is the C-level equivalent of the
+ * one-process-per-GPU path the Python layer runs over torch.distributed. modules[r] must have been built on
+ * engines[r] from the same source and desc; tables in params[r] belong to engines[r]. Several engines may share
+ * a device (how the tests exercise it on one GPU).
+ * ------------------------------------------------------------------------------------------ */
+int mcx_integrate_multi(mcx_engine* const* engines, mcx_module* const* modules, const mcx_integrate_params* const* params,
+                        int n, double* sums_out, uint64_t* n_eff_out);
+int mcx_mcmc_multi(mcx_engine* const* engines, mcx_module* const* modules, const mcx_mcmc_params* const* params,
+                   int n, double* sums_out, uint64_t* n_eff_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,3 +137,41 @@ def test_rccl_all_reduce_is_ordered_after_our_kernels(tmp_path):
     script.write_text(_RCCL_SCRIPT % dict(pkg=str(ROOT / "wgpu-monte-carlo_amd"), root=str(ROOT), port=str(_free_port())))
     res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "RCCL-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+def test_one_thread_drives_several_engines(integrator):
+    """mcx_integrate_multi / mcx_mcmc_multi: the C-level multi-device path (no torch, no RCCL). Three engines on the
+    one GPU of the test box stand in for three devices: same sums as the single-engine call."""
+    import numpy as np
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo import runtime as rt
+    from wgpu_montecarlo.api import functions_to_hip
+
+    fns = [lambda x: x, lambda x: x**2, lambda x: x**3]
+    src = functions_to_hip(fns)
+    beta = Distribution.beta(2.0, 5.0)
+    engines = [rt.Engine(0) for _ in range(3)]
+    try:
+        # K1, custom distribution: every engine owns its copy of the CDF table
+        desc = rt.make_desc(rt.KIND_INTEGRATE, 3, rt.DIST_CUSTOM)
+        shards = [(e, e.module(src, desc), dict(cdf=e.cached_table(rt.TABLE_CDF, beta._cdf_table, beta._x_table))) for e in engines]
+        sums, n_eff = rt.integrate_multi(shards, 3_000_001, 11, 0.0, 0.0)
+        e0, m0, t0 = shards[0]
+        whole, n_eff1 = e0.integrate(m0, 3_000_001, 11, 0.0, 0.0, cdf=t0["cdf"])
+        assert n_eff == n_eff1
+        assert np.allclose(sums, whole, rtol=1e-9, atol=1e-9 * n_eff)
+        # K3, normal proposal (log q from the deviate): chain shards
+        target = Distribution.normal(0.3, 1.0)
+        tx, tl = target.get_log_pdf_table()
+        desc3 = rt.make_desc(rt.KIND_MCMC, 3, rt.DIST_NORMAL, q_sampler=True, cell_tables=True)
+        shards3 = [(e, e.module(src, desc3), dict(target_logpdf=e.cached_table(rt.TABLE_LOGPDF, tx, tl))) for e in engines]
+        sums3, n_eff3 = rt.mcmc_multi(shards3, 300, 2000, 40, 5, 0.0, 2.0)
+        e0, m0, t0 = shards3[0]
+        whole3, _ = e0.mcmc(m0, 300, 2000, 40, 5, 0.0, 2.0, t0["target_logpdf"], None)
+        assert sums3.shape == (4,) and np.allclose(sums3, whole3, rtol=1e-9, atol=1e-9 * n_eff3)
+        # contract errors
+        with pytest.raises(ValueError, match="own engine"):
+            rt.integrate_multi([shards[0], shards[0]], 1000, 1, 0.0, 0.0)
+    finally:
+        for e in engines:
+            e.close()

@@ -70,7 +70,7 @@ EXPORTED_SYMBOLS = [
     "mcx_engine_last_kernel_ms", "mcx_engine_last_launch", "mcx_engine_set_target_threads", "mcx_module_build",
     "mcx_module_precompile", "mcx_result_rows", "mcx_module_source", "mcx_free", "mcx_module_release", "mcx_cache_dir",
     "mcx_table_create", "mcx_table_release", "mcx_table_info", "mcx_table_lds_bytes", "mcx_table_has_cells", "mcx_table_cells", "mcx_integrate", "mcx_integrate_device",
-    "mcx_mcmc", "mcx_mcmc_device",
+    "mcx_mcmc", "mcx_mcmc_device", "mcx_integrate_multi", "mcx_mcmc_multi",
 ]
 
 _lib = None
@@ -155,6 +155,10 @@ def load():
         L.mcx_integrate_device.argtypes = [vp, vp, C.POINTER(IntegrateParams), vp, vp, C.POINTER(u64)]
         L.mcx_mcmc.argtypes = [vp, vp, C.POINTER(McmcParams), C.POINTER(C.c_double), C.POINTER(u64)]
         L.mcx_mcmc_device.argtypes = [vp, vp, C.POINTER(McmcParams), vp, vp, C.POINTER(u64)]
+        L.mcx_integrate_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(C.POINTER(IntegrateParams)), C.c_int,
+                                          C.POINTER(C.c_double), C.POINTER(u64)]
+        L.mcx_mcmc_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(C.POINTER(McmcParams)), C.c_int,
+                                     C.POINTER(C.c_double), C.POINTER(u64)]
         _lib = L
         return _lib
 
@@ -452,6 +456,38 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+
+def _multi(fn_name: str, shards, make_params, ptype):
+    """shards: [(Engine, Module, tables-dict)], one per device; one host thread enqueues all of them, then the K
+    doubles of each are added on the host (include/mcx.h: mcx_integrate_multi / mcx_mcmc_multi)."""
+    n = len(shards)
+    params = [make_params(r, n, eng, tables) for r, (eng, _, tables) in enumerate(shards)]
+    engines = (C.c_void_p * n)(*[eng._h for eng, _, _ in shards])
+    modules = (C.c_void_p * n)(*[mod._h for _, mod, _ in shards])
+    pptr = (C.POINTER(ptype) * n)(*[C.pointer(p) for p in params])
+    sums = np.zeros(result_rows(shards[0][1].desc), dtype=np.float64)
+    n_eff = C.c_uint64(0)
+    check(getattr(load(), fn_name)(engines, modules, pptr, n, sums.ctypes.data_as(C.POINTER(C.c_double)), C.byref(n_eff)))
+    return sums, int(n_eff.value)
+
+
+def integrate_multi(shards, n_samples: int, seed: int, param1: float, param2: float, target_threads: Optional[int] = None):
+    """Whole-grid sums from len(shards) engines driven by this thread. tables-dict keys: cdf, target_pdf, proposal_pdf."""
+    def make(r, n, eng, tb):
+        return IntegrateParams(int(n_samples), int(target_threads or 0), int(seed) & 0xFFFFFFFF, float(param1), float(param2),
+                               r, n, Engine._ptr(tb.get("cdf")), Engine._ptr(tb.get("target_pdf")), Engine._ptr(tb.get("proposal_pdf")))
+    return _multi("mcx_integrate_multi", shards, make, IntegrateParams)
+
+
+def mcmc_multi(shards, n_steps: int, n_chains: int, n_burnin: int, seed: int, param1: float, param2: float,
+               target_threads: Optional[int] = None, x0: float = 0.0):
+    """Chain-sharded MH over len(shards) engines. tables-dict keys: cdf, target_logpdf, proposal_logpdf."""
+    def make(r, n, eng, tb):
+        return McmcParams(int(n_steps), int(n_chains), int(n_burnin), int(target_threads or 0), int(seed) & 0xFFFFFFFF,
+                          float(param1), float(param2), r, n, Engine._ptr(tb.get("cdf")), Engine._ptr(tb.get("target_logpdf")),
+                          Engine._ptr(tb.get("proposal_logpdf")), float(x0), 0)
+    return _multi("mcx_mcmc_multi", shards, make, McmcParams)
 
 
 atexit.register(Engine.close_shared)
