@@ -1,7 +1,8 @@
 // mcx_kernels.hpp -- the fused Monte-Carlo kernels for gfx950 (wave64, 256 CUs).
 //
 // Translation unit layout (assembled by mcx_runtime.cpp, compiled by hiprtc):
-//     #define MCX_K .. / MCX_DIST .. / MCX_BLOCK .. / MCX_WEIGHT .. / MCX_P_TABLE .. / MCX_Q_TABLE ..
+//     #define MCX_K .. / MCX_DIST .. / MCX_BLOCK .. / MCX_WEIGHT .. / MCX_P_TABLE .. / MCX_Q_TABLE .. / MCX_CELL_TABLES ..
+//             / MCX_Q_SAMPLER .. / MCX_WALK .. / MCX_SECOND_MOMENTS .. / MCX_RNG .. / MCX_UNIT_PARAMS ..
 //     mcx_args.h, mcx_device.hpp
 //     <emitted user functions: user_func_0 .. user_func_{K-1}, optional mcx_pdf_p / mcx_pdf_q>
 //     <generated mcx_eval_all>
@@ -20,7 +21,9 @@
 //   * per-thread sums go f32 registers -> f64 registers every MCX_FLUSH units -> wave64 xor-shuffle
 //     -> LDS across waves -> one contiguous record `partials[workgroup][k]`; a second tiny kernel
 //     folds the records in a fixed order. No [T][K] output buffer, no host-side reduction.
-//   * lookup tables are staged once per workgroup into LDS as interleaved float2.
+//   * lookup tables are staged once per workgroup into LDS: PDF / log-PDF tables on a strict grid as per-cell
+//     {intercept, slope} (one read + one FMA per lookup), others as interleaved {key, value}; CDF tables with their
+//     inverse-CDF slopes and a guide table that bounds the search.
 //   * the importance weight p/q is computed once per sample, not once per function.
 #pragma once
 
