@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Soak: random API calls for a fixed wall time; watches host RSS, free device memory and result sanity.
+
+    python tools/soak.py --seconds 180
+"""
+import argparse
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "wgpu-monte-carlo_amd"))
+from wgpu_montecarlo import Distribution, MonteCarloIntegrator  # noqa: E402
+
+
+def rss_mb():
+    with open(f"/proc/{os.getpid()}/status") as fh:
+        for line in fh:
+            if line.startswith("VmRSS"):
+                return int(line.split()[1]) / 1024.0
+    return 0.0
+
+
+def free_device_mb():
+    import torch
+
+    free, _ = torch.cuda.mem_get_info(0)
+    return free / 2**20
+
+
+def make_fn(c):
+    # a new constant gives a new code object key -> a new module; the body stays in the emitter's subset
+    return [lambda x, c=c: x * c, lambda x, c=c: x * x + c, lambda x, c=c: math.sin(x * c), lambda x, c=c: math.exp(-x * x * c)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    args = ap.parse_args()
+    rng = np.random.default_rng(0)
+    t0 = time.time()
+    calls = 0
+    first = None
+    while time.time() - t0 < args.seconds:
+        kind = int(rng.integers(0, 6))
+        mc = MonteCarloIntegrator(target_threads=int(rng.choice([256, 4096, 65536])), rng=str(rng.choice(["pcg_ref", "philox"])),
+                                  std_error=bool(rng.integers(0, 2)))
+        fns = make_fn(float(rng.integers(1, 40)) / 8.0)[: int(rng.integers(1, 5))]
+        n = int(rng.choice([1000, 100_000, 3_000_000, 50_000_000]))
+        if kind == 0:
+            r = mc.integrate(fns, Distribution.normal(float(rng.normal()), 0.5 + float(rng.random())), n_samples=n, seed=calls)
+        elif kind == 1:
+            r = mc.integrate(fns, Distribution.beta(1.5 + float(rng.random()), 2.0 + float(rng.random()), table_size=int(rng.choice([512, 1001, 2048]))),
+                             n_samples=n, seed=calls)
+        elif kind == 2:
+            r = mc.integrate(fns, Distribution.uniform(-1.0, 2.0 + float(rng.random())), n_samples=n, seed=calls)
+        elif kind == 3:
+            xs = np.linspace(-4, 4, int(rng.choice([300, 512, 1000])))
+            r = mc.integrate_importance_sampling(fns, Distribution.from_pdf_table(xs, np.exp(-0.5 * xs * xs)), Distribution.normal(0.0, 1.5),
+                                                 n_samples=n, seed=calls)
+        elif kind == 4:
+            r = mc.integrate_mcmc(fns, Distribution.normal(0.5, 1.0), Distribution.normal(0.0, 2.0), n_steps=int(rng.choice([10, 200])),
+                                  n_chains=int(rng.choice([100, 4096])), n_burnin=int(rng.choice([0, 20])), seed=calls)
+        else:
+            r = mc.integrate_mcmc(fns, Distribution.normal(0.5, 1.0), Distribution.uniform(-1.0, 1.0), n_steps=int(rng.choice([10, 200])),
+                                  n_chains=int(rng.choice([100, 4096])), n_burnin=int(rng.choice([0, 20])), seed=calls,
+                                  proposal_kind="random_walk")
+        assert np.all(np.isfinite(r.values)), (kind, r.values)
+        calls += 1
+        if calls % 100 == 0:
+            line = dict(calls=calls, seconds=round(time.time() - t0, 1), rss_mb=round(rss_mb(), 1), free_device_mb=round(free_device_mb(), 1))
+            first = first or line
+            print(line, flush=True)
+    print("soak done:", calls, "calls; rss growth since call 100:", round(rss_mb() - first["rss_mb"], 1), "MB;",
+          "device memory change:", round(first["free_device_mb"] - free_device_mb(), 1), "MB")
+
+
+if __name__ == "__main__":
+    main()
