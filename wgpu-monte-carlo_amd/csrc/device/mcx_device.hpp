@@ -317,7 +317,7 @@ MCX_COLD float mcx_table_lookup_cold(const float2* kv, u32 n, float x, int g) {
 // built with cell_tables (every PDF / log-PDF table of the call has cells; the host layer decides per call).
 #if MCX_CELL_TABLES
 MCX_DEV float2 mcx_cell_fetch(const McxTable& tb, float x) {
-    const float gf = fminf(fmaxf((x - tb.k0) * tb.inv_dk, 0.0f), (float)(tb.n - 2u));
+    const float gf = __builtin_amdgcn_fmed3f((x - tb.k0) * tb.inv_dk, 0.0f, (float)(tb.n - 2u));   // clamp in one v_med3_f32
     return tb.cells[(u32)gf];
 }
 #endif

@@ -67,8 +67,16 @@ static constexpr int mcx_unroll = MCX_UNROLL;   // a constant, not the macro, in
 #if MCX_UNIT_PARAMS
 #define MCX_AFFINE(z) (z)
 #else
-#define MCX_AFFINE(z) (a.param1 + a.param2 * (z))
+// mean + std * z as ONE v_fma_f32: an FMA may read a single scalar operand, so the mean has to sit in a vector
+// register. Left to itself the compiler re-materialises it (v_mov_b32 from the SGPR) in every loop iteration; an
+// opaque copy made once per kernel (`mcx_affine_b`, below) stays in its VGPR.
+#define MCX_AFFINE(z) (mcx_affine_b + a.param2 * (z))
 #endif
+MCX_DEV float mcx_in_vgpr(float s) {
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
 
 // Large K: per-thread f64 sums would need 2K VGPRs (K = 32 spills). Instead every MCX_FLUSH units each
 // wave reduces its f32 accumulators with xor-shuffles and lane 0 adds the K wave totals into f64 slots in
@@ -189,8 +197,7 @@ MCX_DEV void mcx_accumulate(float x, const McxIsTables& tb, float* acc) {
 #define MCX_Q_SAMPLER 0
 #endif
 template <int S, class Args>
-MCX_DEV void mcx_accumulate_z(float z, const Args& a, const McxIsTables& tb, float* acc) {
-    const float x = MCX_AFFINE(z);
+MCX_DEV void mcx_accumulate_z(float z, float x, const Args& a, const McxIsTables& tb, float* acc) {
 #if MCX_WEIGHT && MCX_Q_SAMPLER
 #if MCX_P_TABLE
     const float p = mcx_table_lookup(tb.p, x, 0.0f);
@@ -221,6 +228,9 @@ MCX_DEV float mcx_draw(u32 h, const McxIntegrateArgs& a, const McxTable& cdf_tb)
 
 extern "C" __global__ void __launch_bounds__(MCX_BLOCK)
 mcx_integrate_kernel(McxIntegrateArgs a) {
+#if !MCX_UNIT_PARAMS && MCX_DIST == MCX_DIST_NORMAL
+    const float mcx_affine_b = mcx_in_vgpr(a.param1);
+#endif
     u32 lds_off = 0u;
     McxTable cdf_tb = mcx_stage_table(a.cdf, lds_off);
     McxIsTables is_tb;
@@ -288,8 +298,8 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 #if MCX_DIST == MCX_DIST_NORMAL
         float z0, z1;
         mcx_box_muller(h_first, h_second, z0, z1);
-        mcx_accumulate_z<MCX_ACC_S>(z0, a, is_tb, acc);
-        if (n_valid > 1u) mcx_accumulate_z<MCX_ACC_S>(z1, a, is_tb, acc + (MCX_ACC_S - 1));
+        mcx_accumulate_z<MCX_ACC_S>(z0, MCX_AFFINE(z0), a, is_tb, acc);
+        if (n_valid > 1u) mcx_accumulate_z<MCX_ACC_S>(z1, MCX_AFFINE(z1), a, is_tb, acc + (MCX_ACC_S - 1));
 #else
         mcx_accumulate<MCX_ACC_S>(mcx_draw(h_first, a, cdf_tb), is_tb, acc);
         if (n_valid > 1u) mcx_accumulate<MCX_ACC_S>(mcx_draw(h_second, a, cdf_tb), is_tb, acc + (MCX_ACC_S - 1));
@@ -334,8 +344,8 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
             st += 4u * MCX_STATE_STEP;
             float z0, z1;
             mcx_box_muller(h1, h2, z0, z1);
-            mcx_accumulate_z<MCX_ACC_S>(z0, a, is_tb, acc);
-            mcx_accumulate_z<MCX_ACC_S>(z1, a, is_tb, acc + (MCX_ACC_S - 1));
+            mcx_accumulate_z<MCX_ACC_S>(z0, MCX_AFFINE(z0), a, is_tb, acc);
+            mcx_accumulate_z<MCX_ACC_S>(z1, MCX_AFFINE(z1), a, is_tb, acc + (MCX_ACC_S - 1));
         }
         MCX_FLUSH_ACC();
     }
@@ -347,7 +357,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         float z0, z1;
         mcx_box_muller(h1, h2, z0, z1);
         MCX_ZERO_ACC();
-        mcx_accumulate_z<MCX_ACC_S>(z0, a, is_tb, acc);
+        mcx_accumulate_z<MCX_ACC_S>(z0, MCX_AFFINE(z0), a, is_tb, acc);
         MCX_FLUSH_ACC();
     }
 #else
@@ -434,6 +444,9 @@ MCX_DEV float mcx_draw_proposal(u32 h, const McxMcmcArgs& a, const McxTable& cdf
 
 extern "C" __global__ void __launch_bounds__(MCX_BLOCK)
 mcx_mcmc_kernel(McxMcmcArgs a) {
+#if !MCX_UNIT_PARAMS && MCX_DIST == MCX_DIST_NORMAL
+    const float mcx_affine_b = mcx_in_vgpr(a.param1);
+#endif
     u32 lds_off = 0u;
     McxTable cdf_tb = mcx_stage_table(a.cdf, lds_off);
     McxTable lp_tb = mcx_stage_table(a.target_logpdf, lds_off);
