@@ -150,6 +150,10 @@ typedef struct mcx_module_desc {
                                 * MCMC: log q = -z^2 / 2 (+ a constant that cancels); no proposal_logpdf table is bound. The
                                 * reference interpolates a 2048-point table of that function (src/shader_gen.rs:521-526):
                                 * <= 6e-6 below it inside +-7 std, -100 outside (probability 2.6e-12 per draw). */
+    int32_t moment_family;     /* 1 (integrate / importance sampling, no second_moments): the caller guarantees
+                                * user_func_i(x) = x^(i+1) for every i -- the fused-moments workload. Two samples a, b are then
+                                * accumulated together through Newton's identity for (weighted) power sums,
+                                * s_k = (a + b) s_{k-1} - a b s_{k-2}: 3 operations per power per pair instead of 4. */
 } mcx_module_desc;
 
 #define MCX_RNG_PCG_REF 0

@@ -467,3 +467,58 @@ def test_philox_mcmc_matches_its_oracle(kind):
     ok, msg = close(res.values, ref["sums"][:2] / ref["n_eff"], tol=2e-4)
     assert ok, msg
     assert abs(res.values[0] - 0.3) < 0.02 and abs(res.values[1] - 1.09) < 0.03
+
+
+@pytest.mark.parametrize("case", ["beta_k32", "normal_k12", "is_table_k9", "philox_uniform_k16"])
+def test_moment_family_pairs_match_per_sample_evaluation(integrator, case):
+    """desc.moment_family: x, x**2, .., x**K accumulated two samples at a time through Newton's identity
+    s_k = (a + b) s_{k-1} - a b s_{k-2} against the per-sample multiply chain on the same stream, and against the
+    oracle. Sums of powers of samples of mixed sign cancel in both forms; the bound is relative to sum |x|^k."""
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+    from wgpu_montecarlo import runtime as rt
+    from wgpu_montecarlo.api import _moment_family, functions_to_hip
+
+    k = int(case.rsplit("k", 1)[1])
+    fns = [lambda x, p=p: x**p for p in range(1, k + 1)]
+    assert _moment_family(fns)
+    mc = MonteCarloIntegrator(rng="philox" if case.startswith("philox") else "pcg_ref")
+    eng = mc._engine
+    n, seed = 2_000_001, 13
+    src = functions_to_hip(fns)
+    if case == "beta_k32":
+        dist = Distribution.beta(2.0, 5.0)
+        common = dict(kind=rt.KIND_INTEGRATE, k=k, dist_type=rt.DIST_CUSTOM)
+        call = lambda mod: eng.integrate(mod, n, seed, 0.0, 0.0, cdf=mc._cdf_table(dist))
+        res = mc.integrate(fns, dist, n_samples=n, seed=seed)
+        xs = oracle.samples(oracle.CUSTOM, n_samples=n, seed=seed, guard=1, cdf_table=dist._cdf_table, x_table=dist._x_table)
+    elif case == "normal_k12":
+        dist = Distribution.normal(0.2, 0.9)
+        common = dict(kind=rt.KIND_INTEGRATE, k=k, dist_type=rt.DIST_NORMAL)
+        call = lambda mod: eng.integrate(mod, n, seed, 0.2, 0.9)
+        res = mc.integrate(fns, dist, n_samples=n, seed=seed)
+        xs = oracle.samples(oracle.NORMAL, 0.2, 0.9, n_samples=n, seed=seed, guard=1)
+    elif case == "philox_uniform_k16":
+        dist = Distribution.uniform(-1.0, 1.5)
+        common = dict(kind=rt.KIND_INTEGRATE, k=k, dist_type=rt.DIST_UNIFORM, rng=rt.RNG_PHILOX)
+        call = lambda mod: eng.integrate(mod, n, seed, -1.0, 1.5)
+        res = mc.integrate(fns, dist, n_samples=n, seed=seed)
+        xs = None
+    else:
+        xt = np.linspace(-3.0, 3.0, 400)
+        target, proposal = Distribution.from_pdf_table(xt, np.exp(-0.5 * xt * xt)), Distribution.normal(0.0, 1.3)
+        tb = mc._table(rt.TABLE_PDF, target._x_table, target._pdf_table)
+        common = dict(kind=rt.KIND_INTEGRATE, k=k, dist_type=rt.DIST_NORMAL, weight=True, p_table=True, q_sampler=True,
+                      cell_tables=True)
+        call = lambda mod: eng.integrate(mod, n, seed, 0.0, 1.3, target_pdf=tb)
+        res = mc.integrate_importance_sampling(fns, target, proposal, n_samples=n, seed=seed)
+        xs = None
+    plain, n_eff = call(eng.module(src, rt.make_desc(**common)))
+    paired, _ = call(eng.module(src, rt.make_desc(moment_family=True, **common)))
+    scale = np.maximum(np.abs(plain), 1e-3 * n_eff)          # sums of x^k with mixed signs cancel
+    assert np.all(np.abs(paired - plain) <= 3e-6 * scale + 1e-4), (paired, plain)
+    assert np.allclose(res.values * n_eff, paired, rtol=1e-12, atol=1e-9 * n_eff)     # the API took the paired path
+    if xs is not None:
+        xs = xs.astype(np.float64).ravel()
+        want = np.array([(xs**p).sum() for p in range(1, k + 1)])
+        mag = np.array([(np.abs(xs) ** p).sum() for p in range(1, k + 1)])
+        assert np.all(np.abs(paired - want) <= 2e-5 * mag), np.abs(paired - want) / mag

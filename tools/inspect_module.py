@@ -41,7 +41,7 @@ def build(which, fast):
     if which == "c4":
         return functions_to_hip([f1, f2], fast), rt.make_desc(rt.KIND_MCMC, 2, rt.DIST_NORMAL, cell_tables=True, q_sampler=True)
     if which == "c5":
-        return functions_to_hip(k32(), fast), rt.make_desc(rt.KIND_INTEGRATE, 32, rt.DIST_CUSTOM)
+        return functions_to_hip(k32(), fast), rt.make_desc(rt.KIND_INTEGRATE, 32, rt.DIST_CUSTOM, moment_family=True)
     raise SystemExit("unknown module " + which)
 
 

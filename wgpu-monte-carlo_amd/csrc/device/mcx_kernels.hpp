@@ -167,37 +167,38 @@ struct McxIsTables { McxTable p, q; };
 #ifndef MCX_Q_SAMPLER
 #define MCX_Q_SAMPLER 0
 #endif
+#ifndef MCX_MOMENT_FAMILY
+#define MCX_MOMENT_FAMILY 0
+#endif
 
-// acc[k * S] is the accumulator of function k (S = 2: the A/B sample lanes are interleaved, see below).
-template <int S>
-MCX_DEV void mcx_accumulate(float x, const McxIsTables& tb, float* acc) {
+// Importance weight p(x) / q(x) of one sample, computed once per sample and shared by the K functions (the
+// reference re-evaluates p and q inside each of its K wrapper functions); 1 for plain integration.
+MCX_DEV float mcx_weight(float x, const McxIsTables& tb) {
 #if MCX_WEIGHT
 #if MCX_P_TABLE
-    float p = mcx_table_lookup(tb.p, x, 0.0f);
+    const float p = mcx_table_lookup(tb.p, x, 0.0f);
 #else
-    float p = mcx_b2f(mcx_pdf_p(x));
+    const float p = mcx_b2f(mcx_pdf_p(x));
 #endif
 #if MCX_Q_TABLE
-    float q = mcx_table_lookup(tb.q, x, 0.0f);
+    const float q = mcx_table_lookup(tb.q, x, 0.0f);
 #elif MCX_Q_SAMPLER
-    float q = 1.0f;                       // not reached: normal samples go through mcx_accumulate_z
+    const float q = 1.0f;                 // not reached: normal samples take mcx_weight_z
 #else
-    float q = mcx_b2f(mcx_pdf_q(x));
+    const float q = mcx_b2f(mcx_pdf_q(x));
 #endif
-    mcx_eval_all<S>(x, mcx_div(p, q), acc);
+    return mcx_div(p, q);
 #else
-    mcx_eval_all<S>(x, 1.0f, acc);
+    (void)x; (void)tb;
+    return 1.0f;
 #endif
 }
 
 // Normal sampler: the sample is x = mean + std * z. With MCX_Q_SAMPLER the importance weight uses
 // 1/q(x) = std * sqrt(2 pi) * exp(z^2 / 2) from the deviate itself -- one v_exp_f32 and three multiplies instead of
 // evaluating the emitted N(mean, std) density at x (subtract, divide, square, exp, scale) and taking its reciprocal.
-#ifndef MCX_Q_SAMPLER
-#define MCX_Q_SAMPLER 0
-#endif
-template <int S, class Args>
-MCX_DEV void mcx_accumulate_z(float z, float x, const Args& a, const McxIsTables& tb, float* acc) {
+template <class Args>
+MCX_DEV float mcx_weight_z(float z, float x, const Args& a, const McxIsTables& tb) {
 #if MCX_WEIGHT && MCX_Q_SAMPLER
 #if MCX_P_TABLE
     const float p = mcx_table_lookup(tb.p, x, 0.0f);
@@ -205,11 +206,33 @@ MCX_DEV void mcx_accumulate_z(float z, float x, const Args& a, const McxIsTables
     const float p = mcx_b2f(mcx_pdf_p(x));
 #endif
     const float sigma = MCX_UNIT_PARAMS ? 1.0f : a.param2;
-    const float inv_q = (sigma * 2.5066282746310002f) * __builtin_amdgcn_exp2f((z * z) * 0.72134752044448170f);
-    mcx_eval_all<S>(x, p * inv_q, acc);
+    return p * ((sigma * 2.5066282746310002f) * __builtin_amdgcn_exp2f((z * z) * 0.72134752044448170f));
 #else
-    (void)a;
-    mcx_accumulate<S>(x, tb, acc);
+    (void)z; (void)a;
+    return mcx_weight(x, tb);
+#endif
+}
+
+// acc[k * S] is the accumulator of function k (S = 2: the A/B sample lanes are interleaved, see below).
+template <int S>
+MCX_DEV void mcx_accumulate(float x, const McxIsTables& tb, float* acc) {
+    mcx_eval_all<S>(x, mcx_weight(x, tb), acc);
+}
+template <int S, class Args>
+MCX_DEV void mcx_accumulate_z(float z, float x, const Args& a, const McxIsTables& tb, float* acc) {
+    mcx_eval_all<S>(x, mcx_weight_z(z, x, a, tb), acc);
+}
+
+// Two samples at once. MCX_MOMENT_FAMILY (user_func_i(x) = x^(i+1), promised by the caller): the generated
+// mcx_eval_pair accumulates the weighted power sums wa a^k + wb b^k through Newton's identity into the first
+// accumulator set; otherwise each sample goes through mcx_eval_all into its own set.
+template <int S>
+MCX_DEV void mcx_accumulate_pair(float xa, float xb, float wa, float wb, float* acc) {
+#if MCX_MOMENT_FAMILY
+    mcx_eval_pair<S>(xa, xb, wa, wb, acc);
+#else
+    mcx_eval_all<S>(xa, wa, acc);
+    mcx_eval_all<S>(xb, wb, acc + (S - 1));
 #endif
 }
 
@@ -344,8 +367,8 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
             st += 4u * MCX_STATE_STEP;
             float z0, z1;
             mcx_box_muller(h1, h2, z0, z1);
-            mcx_accumulate_z<MCX_ACC_S>(z0, MCX_AFFINE(z0), a, is_tb, acc);
-            mcx_accumulate_z<MCX_ACC_S>(z1, MCX_AFFINE(z1), a, is_tb, acc + (MCX_ACC_S - 1));
+            const float xa = MCX_AFFINE(z0), xb = MCX_AFFINE(z1);
+            mcx_accumulate_pair<MCX_ACC_S>(xa, xb, mcx_weight_z(z0, xa, a, is_tb), mcx_weight_z(z1, xb, a, is_tb), acc);
         }
         MCX_FLUSH_ACC();
     }
@@ -375,8 +398,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
             st += 2u * MCX_STATE_STEP;
             float xA = mcx_draw(hA, a, cdf_tb);
             float xB = mcx_draw(hB, a, cdf_tb);
-            mcx_accumulate<MCX_ACC_S>(xA, is_tb, acc);
-            mcx_accumulate<MCX_ACC_S>(xB, is_tb, acc + (MCX_ACC_S - 1));
+            mcx_accumulate_pair<MCX_ACC_S>(xA, xB, mcx_weight(xA, is_tb), mcx_weight(xB, is_tb), acc);
         }
         if (i < blk_end) {                                   // odd tail of the block
             mcx_accumulate<MCX_ACC_S>(mcx_draw(mcx_pcg_out(st), a, cdf_tb), is_tb, acc);
