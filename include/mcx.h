@@ -194,6 +194,9 @@ int  mcx_table_info(const mcx_table* t, uint32_t* n, float* inv_dk, uint32_t* gu
 /* LDS bytes a launch stages for this table (key/value pairs or cells, CDF slopes, guide): what a module built with
  * tables_lds = 1 needs per workgroup for it. */
 uint32_t mcx_table_lds_bytes(const mcx_table* t);
+/* Host-side: the index map of the cell form, idx = floor(x * scale + c0) clamped to [0, n]: 1 + c is cell c, 0 and n
+ * are sentinel cells {outside value, slope 0} for x left / right of the table (both table ends map inside). */
+int  mcx_table_cell_map(const float* keys, uint32_t n, float* scale_out, float* c0_out);
 /* 1 if the table was stored with slope-intercept cells (PDF / log-PDF kinds on a strict f32-linspace grid), else 0. */
 int  mcx_table_has_cells(const mcx_table* t);
 int  mcx_table_cells(const float* keys, const float* values, uint32_t n, float* cells_out);

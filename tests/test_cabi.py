@@ -181,3 +181,28 @@ def test_table_cells_strict_grid_and_accuracy():
     assert rt.table_cells(tx, tl) is not None
     d = Distribution.from_pdf_table(np.linspace(0, 10, 512), np.exp(-np.linspace(0, 10, 512)))
     assert rt.table_cells(d._x_table, d._pdf_table) is not None
+
+
+@pytest.mark.parametrize("lo,hi,n", [(-9.0, 9.0, 2048), (0.0, 10.0, 512), (-10.0, 10.0, 4096), (100.0, 101.0, 300), (-6.0, 6.0, 65536)])
+def test_cell_index_map_keeps_both_table_ends_inside(lo, hi, n):
+    """idx = floor(fma(x, scale, c0)) clamped to [0, n]: 0 / n are the outside sentinels, 1 + c is cell c. Every key,
+    both end points included, must land in a real cell next to it; points clearly outside must hit a sentinel."""
+    keys = np.linspace(lo, hi, n).astype(np.float32)
+    scale, c0 = rt.table_cell_map(keys)
+    fma = lambda x: (x.astype(np.float64) * float(scale) + float(c0)).astype(np.float32)
+    idx = np.clip(np.floor(fma(keys)), 0, n).astype(np.int64)
+    assert idx[0] == 1 and idx[-1] == n - 1
+    want = np.arange(n) + 1                    # node i opens cell i (padded index i + 1); the last node closes cell n - 2
+    assert np.all((idx == want) | (idx == want - 1))
+    dk = (hi - lo) / (n - 1)
+    rng = np.random.default_rng(1)
+    x = rng.uniform(lo, hi, 200_000).astype(np.float32)
+    true_cell = np.clip(np.floor((x.astype(np.float64) - lo) / dk), 0, n - 2).astype(np.int64) + 1
+    got = np.clip(np.floor(fma(x)), 0, n).astype(np.int64)
+    assert np.all(np.abs(got - true_cell) <= 1)
+    frac = (x.astype(np.float64) - lo) / dk % 1.0
+    off = got != true_cell                      # only next to a node
+    assert np.all(np.minimum(frac[off], 1 - frac[off]) < 0.08)
+    outside = np.array([lo - 0.2 * dk - abs(lo) * 1e-6, hi + 0.2 * dk + abs(hi) * 1e-6, lo - 5 * dk, hi + 5 * dk], np.float32)
+    got_out = np.clip(np.floor(fma(outside)), 0, n).astype(np.int64)
+    assert list(got_out) == [0, n, 0, n]

@@ -2,7 +2,7 @@
 # A/B of K3 / K2 lookup variants on the GPU box: tools/ab_c4.sh  (run through gpurun from the repo root)
 set -u
 mkdir -p gpurun_out
-IFS="|" read -r -a VARIANTS <<< "${VARIANTS:-|MCX_LOOKUP_BRANCHLESS=0||MCX_LOOKUP_BRANCHLESS=0}"
+IFS="|" read -r -a VARIANTS <<< "${VARIANTS:-|}"
 for defs in "${VARIANTS[@]}"; do
   echo "== MCX_EXTRA_DEFINES='$defs'"
   MCX_EXTRA_DEFINES="$defs" timeout -k 10 200 python tools/run_configs.py --only ${ONLY:-C3,C4,C4RW} --repeat ${REPEAT:-6} 2>/dev/null | python -c "

@@ -22,9 +22,12 @@ typedef struct McxTableDesc {
     mcx_u32 n;
     mcx_u32 guide_bits;
     float   inv_dk;         // (n-1)/(key[n-1]-key[0]) if the keys form a uniform grid, else 0
-    mcx_u32 _pad;
-    const float* cells;     // device pointer, n-1 {intercept, slope} pairs (PDF / log-PDF tables on a strict grid), or null
+    float   cell_c0;        // cell index (with the leading sentinel) = floor(x * cell_scale + cell_c0), see cell_map()
+    const float* cells;     // device pointer, n+1 {intercept, slope} pairs: {outside, 0}, the n-1 cells, {outside, 0}
+                            // (PDF / log-PDF tables on a strict grid), or null
     const float* slopes;    // device pointer, n inverse-CDF slopes dx/dcdf per cell (CDF tables), or null
+    float   cell_scale;
+    mcx_u32 _pad1;
 } McxTableDesc;
 
 // K1 / K2: plain and importance-sampling integration.

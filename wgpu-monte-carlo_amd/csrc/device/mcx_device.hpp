@@ -181,12 +181,6 @@ MCX_DEV void mcx_box_muller(u32 h1, u32 h2, float& z0, float& z1) {
 #define MCX_CELL_TABLES 0
 #endif
 
-// Cell lookups: keep the LDS read unconditional (1) or let the compiler sink it into an exec-masked block for the
-// in-range lanes (0). Measured: K2 (C3) 0.99 ms vs 1.07 ms in favour of 1, K3 (C4) 13.55 ms vs 13.4 ms in favour of 0.
-#ifndef MCX_LOOKUP_BRANCHLESS
-#define MCX_LOOKUP_BRANCHLESS (MCX_KIND == 0)
-#endif
-
 struct McxTable {
     const float2* kv;     // LDS or global
     u32   n;
@@ -194,7 +188,9 @@ struct McxTable {
     float inv_dk;         // (n-1)/(k[n-1]-k[0]) when the keys are a uniform grid, else 0
     const u32* guide;     // CDF only: guide[b] = lo | hi << 16, the search window of bucket b, or null
     u32   guide_bits;     // number of buckets G = 1 << guide_bits
-    const float2* cells;  // PDF / log-PDF on a strict grid: cells[c] = {intercept, slope} of cell c, else null (then kv is set)
+    const float2* cells;  // PDF / log-PDF on a strict grid: cells[1 + c] = {intercept, slope} of cell c, cells[0] and
+                          // cells[n] = {outside, 0} for x left / right of the table; else null (then kv is set)
+    float cell_scale, cell_c0;   // padded cell index = floor(x * cell_scale + cell_c0) (host: cell_map)
     const float* slopes;  // CDF: slopes[c] = dx/dcdf of cell c (0 for cells narrower than 1e-10), or null
 };
 
@@ -317,7 +313,9 @@ MCX_COLD float mcx_table_lookup_cold(const float2* kv, u32 n, float x, int g) {
 // built with cell_tables (every PDF / log-PDF table of the call has cells; the host layer decides per call).
 #if MCX_CELL_TABLES
 MCX_DEV float2 mcx_cell_fetch(const McxTable& tb, float x) {
-    const float gf = __builtin_amdgcn_fmed3f((x - tb.k0) * tb.inv_dk, 0.0f, (float)(tb.n - 2u));   // clamp in one v_med3_f32
+    // floor(x * scale + c0) clamped to [0, n] in one v_fma_f32 + one v_med3_f32: 0 and n are the {outside, 0}
+    // sentinels, so lanes outside the table need no compare / select afterwards; both table ends map inside.
+    const float gf = __builtin_amdgcn_fmed3f(fmaf(x, tb.cell_scale, tb.cell_c0), 0.0f, (float)tb.n);
     return tb.cells[(u32)gf];
 }
 #endif
@@ -327,14 +325,9 @@ MCX_DEV float mcx_table_lookup(const McxTable& tb, float x, float outside) {
     const u32 n = tb.n;
     const bool out_of_range = (x < tb.k0) || (x > tb.k1);
 #if MCX_CELL_TABLES
-    (void)kv;
-    float2 c = mcx_cell_fetch(tb, x);
-#if MCX_LOOKUP_BRANCHLESS
-    // keep the read unconditional: otherwise the compiler sinks it into an exec-masked block per lookup, which
-    // serialises the LDS round trips of a step's lookups behind scalar branches
-    asm volatile("" : "+v"(c.x), "+v"(c.y));
-#endif
-    return out_of_range ? outside : fmaf(c.y, x, c.x);
+    (void)kv; (void)n; (void)out_of_range; (void)outside;
+    const float2 c = mcx_cell_fetch(tb, x);
+    return fmaf(c.y, x, c.x);
 #else
     float v;
 #if MCX_UNIFORM_TABLES

@@ -101,6 +101,8 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
     t.guide = nullptr;
     t.kv = nullptr;
     t.cells = nullptr;
+    t.cell_c0 = d.cell_c0;
+    t.cell_scale = d.cell_scale;
     t.slopes = nullptr;
     t.k0 = 0.0f;
     t.k1 = 0.0f;
@@ -113,9 +115,9 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
 #if MCX_TABLES_LDS
     float2* dst = (float2*)(mcx_lds_raw + off);
     const float2* src = (const float2*)(cell_form ? d.cells : d.kv);
-    const u32 count = cell_form ? d.n - 1u : d.n;
+    const u32 count = cell_form ? d.n + 1u : d.n;       // cell form: two sentinels + n - 1 cells
     for (u32 i = threadIdx.x; i < count; i += MCX_BLOCK) dst[i] = src[i];
-    off += d.n * 8u;
+    off += count * 8u;
     if (cell_form) t.cells = dst; else t.kv = dst;
     if (d.slopes != nullptr) {
         float* sdst = (float*)(mcx_lds_raw + off);

@@ -28,6 +28,7 @@ void analyse_table(int kind, const float* keys, uint32_t n, float* inv_dk, std::
 // returns x[c] because the cell is narrower than 1e-10, distribution.rs:152-155), slope[n-1] = 0.
 void build_cdf_slopes(const float* cdf, const float* x, uint32_t n, std::vector<float>* slopes);
 
+void cell_map(const float* keys, uint32_t n, float* scale, float* c0);
 void build_cells(const float* keys, const float* values, uint32_t n, std::vector<float>* cells);
 
 }  // namespace mcx

@@ -161,6 +161,19 @@ void build_cdf_slopes(const float* cdf, const float* x, uint32_t n, std::vector<
     }
 }
 
+// Index map of the sentinel-padded cell array: idx = floor(x * scale + c0) clamped to [0, n]; 0 and n are the
+// {outside, 0} sentinels, 1 + c is cell c. Both table ends are INSIDE (the reference interpolates at x == key[0] and
+// x == key[n-1]; a CDF-sampled x lands exactly on key[n-1] about 3e-8 of the time), so the grid is shrunk by eps cells
+// at either end: key[0] maps to 1 + eps and key[n-1] to n - eps. eps also has to cover the rounding of the f32 FMA
+// (about n * 2^-23 cells); a lane within eps cells outside the table extends the end cell's line that far.
+void cell_map(const float* keys, uint32_t n, float* scale, float* c0) {
+    const double k0 = keys[0], span = (double)keys[n - 1u] - k0;
+    const double eps = std::fmax(1.0 / 512.0, (double)n / 1048576.0);
+    const double s = ((double)(n - 1u) - 2.0 * eps) / span;
+    *scale = (float)s;
+    *c0 = (float)(1.0 + eps - k0 * (double)*scale);
+}
+
 void build_cells(const float* keys, const float* values, uint32_t n, std::vector<float>* cells) {
     cells->clear();
     if (n < 2u) return;

@@ -70,7 +70,7 @@ EXPORTED_SYMBOLS = [
     "mcx_shard_units", "mcx_shard_chains", "mcx_device_count", "mcx_engine_create", "mcx_engine_destroy", "mcx_engine_device",
     "mcx_engine_last_kernel_ms", "mcx_engine_last_launch", "mcx_engine_set_target_threads", "mcx_module_build",
     "mcx_module_precompile", "mcx_result_rows", "mcx_module_source", "mcx_free", "mcx_module_release", "mcx_cache_dir",
-    "mcx_table_create", "mcx_table_release", "mcx_table_info", "mcx_table_lds_bytes", "mcx_table_has_cells", "mcx_table_cells", "mcx_integrate", "mcx_integrate_device",
+    "mcx_table_create", "mcx_table_release", "mcx_table_info", "mcx_table_lds_bytes", "mcx_table_cell_map", "mcx_table_has_cells", "mcx_table_cells", "mcx_integrate", "mcx_integrate_device",
     "mcx_mcmc", "mcx_mcmc_device", "mcx_integrate_multi", "mcx_mcmc_multi",
 ]
 
@@ -148,6 +148,7 @@ def load():
         L.mcx_table_release.argtypes = [vp]
         L.mcx_table_release.restype = None
         L.mcx_table_info.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(u32)]
+        L.mcx_table_cell_map.argtypes = [C.POINTER(C.c_float), u32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mcx_table_has_cells.argtypes = [vp]
         L.mcx_table_lds_bytes.argtypes = [vp]
         L.mcx_table_lds_bytes.restype = u32
@@ -232,6 +233,14 @@ def table_cells(keys, values):
     if rc < 0:
         check(rc)
     return out if rc == 1 else None
+
+
+def table_cell_map(keys):
+    """(scale, c0) of the cell form's index map idx = floor(x * scale + c0) (include/mcx.h: mcx_table_cell_map)."""
+    k = np.ascontiguousarray(keys, dtype=np.float32)
+    scale, c0 = C.c_float(0), C.c_float(0)
+    check(load().mcx_table_cell_map(k.ctypes.data_as(C.POINTER(C.c_float)), len(k), C.byref(scale), C.byref(c0)))
+    return np.float32(scale.value), np.float32(c0.value)
 
 
 def result_rows(desc: ModuleDesc) -> int:
