@@ -242,3 +242,41 @@ def test_oversubscribed_reference_stream_warns():
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         MonteCarloIntegrator(rng="philox").integrate([lambda x: x * x], D().normal(0.0, 1.0), n_samples=5_000_000_000)
+
+
+def test_concurrent_host_threads_share_one_engine(mc):
+    """SURVEY 8(b) threading row: ctypes releases the GIL, the engine serialises launches with its own mutex. Four
+    threads hammer the shared engine with different calls; every result equals the single-threaded one."""
+    import threading
+
+    Distribution = D()
+    fns = [lambda x: x, lambda x: x * x]
+    jobs = [("k1", Distribution.normal(0.0, 1.0), 300_001, 3), ("k1", Distribution.beta(2.0, 5.0), 200_003, 4),
+            ("k1", Distribution.uniform(-1.0, 2.0), 100_001, 5), ("k3", None, 0, 6)]
+
+    def run(job):
+        kind, dist, n, seed = job
+        if kind == "k1":
+            return mc.integrate(fns, dist, n_samples=n, seed=seed).values
+        return mc.integrate_mcmc(fns, Distribution.normal(0.3, 1.0), Distribution.normal(0.0, 2.0), n_steps=200,
+                                 n_chains=512, n_burnin=20, seed=seed).values
+
+    expected = [run(j) for j in jobs]
+    errors = []
+
+    def worker(i):
+        try:
+            for rep in range(25):
+                j = (i + rep) % len(jobs)
+                got = run(jobs[j])
+                if not np.array_equal(got, expected[j]):
+                    errors.append((i, rep, j, got, expected[j]))
+        except Exception as exc:      # noqa: BLE001
+            errors.append((i, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
