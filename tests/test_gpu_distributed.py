@@ -95,6 +95,32 @@ def test_device_resident_launch_follows_torch_streams(integrator):
     assert np.array_equal(prepared.run(50_000_000, 3).values, want.values)
 
 
+def test_launches_on_two_streams_do_not_share_scratch(integrator):
+    """Two torch streams launch on the same engine in alternation: each stream has its own per-workgroup partials
+    buffer (the fold kernel reads what the main kernel of the same launch wrote), so the results are the blocking ones."""
+    import torch
+
+    from wgpu_montecarlo import Distribution
+
+    fns = [lambda x: x, lambda x: x**2]
+    prepared = integrator.prepare_integrate(fns, Distribution.normal(0.0, 1.0))
+    n = 30_000_000
+    want = [prepared.run(n, seed).values for seed in range(8)]
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    out = torch.zeros(16, 2, dtype=torch.float64, device=dev)
+    n_eff = None
+    for rep in range(2):
+        for seed in range(8):
+            with torch.cuda.stream(streams[seed % 2]):
+                n_eff = prepared.launch(n, seed, out[rep * 8 + seed])
+    torch.cuda.synchronize()
+    got = out.cpu().numpy() / float(n_eff)
+    for rep in range(2):
+        for seed in range(8):
+            assert np.array_equal(got[rep * 8 + seed], want[seed]), (rep, seed)
+
+
 _RCCL_SCRIPT = r"""
 import os, sys
 sys.path[:0] = [%(pkg)r, %(root)r]
