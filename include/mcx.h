@@ -154,6 +154,12 @@ typedef struct mcx_module_desc {
                                 * user_func_i(x) = x^(i+1) for every i -- the fused-moments workload. Two samples a, b are then
                                 * accumulated together through Newton's identity for (weighted) power sums,
                                 * s_k = (a + b) s_{k-1} - a b s_{k-2}: 3 operations per power per pair instead of 4. */
+    int32_t user_tables;       /* integrate modules: bit 0 / bit 1 = the target / proposal PDF table of the call is staged and
+                                * visible to the user functions through the device functions mcx_user_pdf_target and mcx_user_pdf_proposal -- what the
+                                * reference's own importance-sampling wrappers call as pdf_target_from_table(x) /
+                                * pdf_proposal_from_table(x) (src/distribution.rs:181-223, python/wgpu_montecarlo/
+                                * __init__.py:968-974). For callers that hand over the reference's WGSL text unchanged
+                                * (wgpu_montecarlo/_core.py); the package's own API uses the weight mode instead. */
 } mcx_module_desc;
 
 #define MCX_RNG_PCG_REF 0

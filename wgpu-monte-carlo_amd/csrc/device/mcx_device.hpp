@@ -352,6 +352,19 @@ MCX_DEV float mcx_table_lookup(const McxTable& tb, float x, float outside) {
 #endif
 }
 
+// The importance-sampling tables of a launch. With MCX_USER_TABLES they are also visible to user functions: the
+// reference's IS wrappers are WGSL text that calls pdf_target_from_table(x) / pdf_proposal_from_table(x)
+// (python/wgpu_montecarlo/__init__.py:968-974), which the WGSL translator maps to the two accessors below.
+struct McxIsTables { McxTable p, q; };
+#ifndef MCX_USER_TABLES
+#define MCX_USER_TABLES 0
+#endif
+#if MCX_USER_TABLES
+__shared__ McxIsTables mcx_user_tables;
+MCX_DEV float mcx_user_pdf_target(float x)   { return mcx_table_lookup(mcx_user_tables.p, x, 0.0f); }
+MCX_DEV float mcx_user_pdf_proposal(float x) { return mcx_table_lookup(mcx_user_tables.q, x, 0.0f); }
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // WGSL builtins the emitter may call (semantics: W3C WGSL; reference FUNC_MAP transpiler.py:82-112)
 // ---------------------------------------------------------------------------------------------

@@ -165,7 +165,6 @@ MCX_DEV void mcx_block_reduce_store(double (&v)[N], double* partials) {
 // =============================================================================================
 // K1 / K2: fused sample + (weight) + K evaluations + reduction
 // =============================================================================================
-struct McxIsTables { McxTable p, q; };
 #ifndef MCX_Q_SAMPLER
 #define MCX_Q_SAMPLER 0
 #endif
@@ -262,6 +261,9 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
     is_tb.p = mcx_stage_table(a.target_pdf, lds_off);
     is_tb.q = mcx_stage_table(a.proposal_pdf, lds_off);
     (void)cdf_tb;
+#if MCX_USER_TABLES
+    if (threadIdx.x == 0u) mcx_user_tables = is_tb;          // user functions read them through mcx_user_pdf_*()
+#endif
     __syncthreads();
 
     // idx_count is a multiple of 64 (whole reference workgroups; checked on the host), so the 64 lanes of

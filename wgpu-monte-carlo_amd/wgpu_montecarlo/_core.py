@@ -1,0 +1,130 @@
+"""`_core`-level drop-in: the interface of the reference's native module over libmcx.so.
+
+The reference's Python half calls `self._integrator.integrate / integrate_is_tables / integrate_mcmc` on the PyO3
+class `_core.MonteCarloIntegrator` (src/lib.rs:17-431; call sites python/wgpu_montecarlo/__init__.py:761-770,
+994-1007, 1096-1113) and hands it *WGSL text*. This module offers the same class -- same method names, positional
+signatures, defaults, return type (float32[K]) and exception types -- so that the reference's own `__init__.py` and
+`transpiler.py` could run unchanged on an MI355X. The WGSL strings (the transpiler's output, user strings and the
+importance-sampling wrappers that call `pdf_target_from_table` / `pdf_proposal_from_table`) are translated literally
+to HIP C++ (wgsl_to_hip.py) and fused into the same kernels; nothing here takes the faster routes of this package's
+own API (api.py): weights are evaluated per function as the wrapper text says, and every table lookup runs the
+search-and-blend form.
+
+It is a binding, not a second implementation: planning, compilation, tables, launches and the f64 reduction are
+libmcx's (include/mcx.h).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import runtime, wgsl_to_hip
+
+_DIST = {"uniform": runtime.DIST_UNIFORM, "normal": runtime.DIST_NORMAL, "exponential": runtime.DIST_EXPONENTIAL,
+         "custom": runtime.DIST_CUSTOM}
+
+
+def _params(dist_type: str, params: dict):
+    """src/lib.rs:436-502, including its silent defaults and its error for unknown names."""
+    if dist_type not in _DIST:
+        raise ValueError(f"Unknown distribution type: {dist_type}")
+
+    def num(key, default):
+        try:
+            return float(params.get(key, default))
+        except (TypeError, ValueError):
+            return float(default)
+
+    if dist_type == "uniform":
+        return _DIST[dist_type], num("min", 0.0), num("max", 1.0)
+    if dist_type == "normal":
+        return _DIST[dist_type], num("mean", 0.0), num("std", 1.0)
+    if dist_type == "exponential":
+        return _DIST[dist_type], num("lambda", 1.0), 0.0
+    return _DIST[dist_type], 0.0, 0.0
+
+
+def _f32(a) -> Optional[np.ndarray]:
+    """numpy inputs are copied as f32; a non-contiguous array silently becomes empty in the reference
+    (`as_slice().unwrap_or(&[])`, src/lib.rs:71-77) -- here it is simply made contiguous."""
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+class MonteCarloIntegrator:
+    """Replaces `_core.MonteCarloIntegrator` (src/lib.rs:17-431)."""
+
+    def __init__(self, device: int = 0):
+        self._engine = runtime.Engine.shared(device)           # RuntimeError("Failed to initialize GPU: ...")
+
+    # ---- helpers ----------------------------------------------------------------------------------
+    @staticmethod
+    def _source(functions: Sequence[str]) -> str:
+        if len(functions) == 0:
+            raise ValueError("At least one function is required")          # src/lib.rs:61-65
+        return "\n\n".join(wgsl_to_hip.translate(text, i, f"user_func_{i}") for i, text in enumerate(functions))
+
+    def _cdf(self, dist_type: str, x_table, cdf_table):
+        if dist_type != "custom":
+            return None
+        x, c = _f32(x_table), _f32(cdf_table)
+        if x is None or c is None:
+            raise RuntimeError("Failed to setup integration: custom distribution requires x_table and cdf_table")
+        return self._engine.cached_table(runtime.TABLE_CDF, c, x)
+
+    def _result(self, sums: np.ndarray, k: int, n_eff: int) -> np.ndarray:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return (sums[:k] / float(n_eff)).astype(np.float32)
+
+    # ---- src/lib.rs:47-141 ------------------------------------------------------------------------
+    def integrate(self, functions, dist_type, dist_params, n_samples, seed, x_table=None, cdf_table=None,
+                  target_threads=None) -> np.ndarray:
+        src = self._source(functions)
+        code, p1, p2 = _params(dist_type, dist_params)
+        cdf = self._cdf(dist_type, x_table, cdf_table)
+        desc = runtime.make_desc(runtime.KIND_INTEGRATE, len(functions), code, guard_endpoints=True)
+        mod = self._engine.module(src, desc)
+        sums, n_eff = self._engine.integrate(mod, int(n_samples), int(seed), p1, p2, target_threads, cdf=cdf)
+        return self._result(sums, len(functions), n_eff)
+
+    # ---- src/lib.rs:158-275 -----------------------------------------------------------------------
+    def integrate_is_tables(self, functions, dist_type, dist_params, n_samples, seed, x_table=None, cdf_table=None,
+                            target_x_table=None, target_pdf_table=None, proposal_x_table=None,
+                            proposal_pdf_table=None, target_threads=None) -> np.ndarray:
+        src = self._source(functions)
+        code, p1, p2 = _params(dist_type, dist_params)
+        cdf = self._cdf(dist_type, x_table, cdf_table)
+        mask, tables = 0, {}
+        if target_x_table is not None and target_pdf_table is not None:
+            tables["target_pdf"] = self._engine.cached_table(runtime.TABLE_PDF, _f32(target_x_table), _f32(target_pdf_table))
+            mask |= 1
+        if proposal_x_table is not None and proposal_pdf_table is not None:
+            tables["proposal_pdf"] = self._engine.cached_table(runtime.TABLE_PDF, _f32(proposal_x_table), _f32(proposal_pdf_table))
+            mask |= 2
+        desc = runtime.make_desc(runtime.KIND_INTEGRATE, len(functions), code, guard_endpoints=True, user_tables=mask)
+        mod = self._engine.module(src, desc)
+        sums, n_eff = self._engine.integrate(mod, int(n_samples), int(seed), p1, p2, target_threads, cdf=cdf, **tables)
+        return self._result(sums, len(functions), n_eff)
+
+    # ---- src/lib.rs:296-431 -----------------------------------------------------------------------
+    def integrate_mcmc(self, functions, proposal_dist_type, proposal_dist_params, target_dist_type, target_dist_params,
+                       n_steps, n_chains, n_burnin, seed, x_table=None, cdf_table=None, target_x_table=None,
+                       target_log_pdf_table=None, proposal_x_table=None, proposal_log_pdf_table=None,
+                       target_threads=None) -> np.ndarray:
+        src = self._source(functions)
+        if int(n_steps) == 0:
+            raise ValueError("n_steps must be positive")                    # src/lib.rs:332-336
+        if int(n_chains) == 0:
+            raise ValueError("n_chains must be positive")                   # src/lib.rs:338-342
+        code, p1, p2 = _params(proposal_dist_type, proposal_dist_params)
+        _params(target_dist_type, target_dist_params)                       # validated like the reference, then unused
+        cdf = self._cdf(proposal_dist_type, x_table, cdf_table)
+        if target_x_table is None or target_log_pdf_table is None or proposal_x_table is None or proposal_log_pdf_table is None:
+            raise RuntimeError("Failed to setup MCMC: target and proposal log-PDF tables are required")
+        t = self._engine.cached_table(runtime.TABLE_LOGPDF, _f32(target_x_table), _f32(target_log_pdf_table))
+        q = self._engine.cached_table(runtime.TABLE_LOGPDF, _f32(proposal_x_table), _f32(proposal_log_pdf_table))
+        desc = runtime.make_desc(runtime.KIND_MCMC, len(functions), code, guard_endpoints=True)
+        mod = self._engine.module(src, desc)
+        sums, n_eff = self._engine.mcmc(mod, int(n_steps), int(n_chains), int(n_burnin), int(seed), p1, p2, t, q,
+                                        target_threads=target_threads, cdf=cdf)
+        return self._result(sums, len(functions), n_eff)

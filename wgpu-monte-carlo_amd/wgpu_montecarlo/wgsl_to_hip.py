@@ -27,6 +27,10 @@ _TOKEN = re.compile(
 
 _TYPES = {"f32": "float", "f16": "float", "i32": "int", "u32": "unsigned int", "bool": "bool"}
 
+# the table lookups the reference's importance-sampling wrappers call (python/wgpu_montecarlo/__init__.py:968-974;
+# defined by its shader template, src/distribution.rs:181-223): device accessors of a module built with user_tables
+_TABLE_CALLS = {"pdf_target_from_table": "mcx_user_pdf_target", "pdf_proposal_from_table": "mcx_user_pdf_proposal"}
+
 _BUILTINS = {
     "abs": "fabsf", "sin": "sinf", "cos": "cosf", "tan": "tanf", "asin": "asinf", "acos": "acosf",
     "atan": "atanf", "atan2": "atan2f", "sinh": "sinhf", "cosh": "coshf", "tanh": "tanhf",
@@ -176,6 +180,8 @@ class _Parser:
                 return f"(({args[2]}) ? ({args[1]}) : ({args[0]}))"
             if value in _BUILTINS:
                 return f"{_BUILTINS[value]}({', '.join(args)})"
+            if value in _TABLE_CALLS and value not in self.local_functions:
+                return f"{_TABLE_CALLS[value]}({', '.join(args)})"
             if value in self.local_functions:
                 return f"{self.fn_name(value)}({', '.join(args)})"
             if value.startswith("vec") or value.startswith("mat") or value == "array":
