@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the CPU baseline slice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--target-phys", type=int, default=0, help="physical threads per launch (tuning)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the independent steps are issued on in turn (2: the next step's workgroups fill "
+                         "the CUs the previous step's tail leaves idle)")
     ap.add_argument("--rng", default="pcg_ref", help="pcg_ref (the reference's stream; the headline) or philox")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the measured configuration) or gloo (rehearsal)")
     ap.add_argument("--single-device", action="store_true",
@@ -130,10 +133,14 @@ def main():
     out = torch.zeros(args.warmup + args.steps + 1, K, dtype=torch.float64, device=device)
 
     pending = []
+    # steps are independent integrals (own seed, own row of `out`): issuing them on alternating streams lets the next
+    # step's workgroups start while the previous step's last workgroups drain (one engine, per-stream scratch)
+    streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.streams))]
 
     def step(i):
         # the all-reduce of step i overlaps the kernel of step i + 1 (different rows of `out`)
-        n_eff_, work = prepared.launch(n_total, 42 + i, out[i], async_op=True)
+        with torch.cuda.stream(streams[i % len(streams)]):
+            n_eff_, work = prepared.launch(n_total, 42 + i, out[i], async_op=True)
         if work is not None:
             pending.append(work)
         return n_eff_
@@ -209,7 +216,7 @@ def main():
                 "parallelism": (f"sample-grid shards x{world}, one {'RCCL' if args.backend == 'nccl' else args.backend} "
                                 f"sum all-reduce of {K} f64 per step") if world > 1 else "single GPU",
                 "accumulate": "f32 registers per 128 pairs -> f64",
-                "rng": args.rng,
+                "rng": args.rng, "streams": len(streams),
                 "hip_runtime": integ_runtime,
             },
             "abs_err_vs_truth": abs_err.max(axis=0).tolist(),

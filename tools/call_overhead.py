@@ -43,3 +43,27 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def device_path():
+    """Kernel time (HIP events) of PreparedIntegrand.launch on torch streams, one launch at a time."""
+    import torch
+
+    mc = MonteCarloIntegrator()
+    prepared = mc.prepare_integrate([f1, f2, f3, f4], Distribution.normal(0.0, 1.0))
+    dev = torch.device("cuda", 0)
+    out = torch.zeros(4, dtype=torch.float64, device=dev)
+    for label, stream in (("null stream", None), ("side stream", torch.cuda.Stream(device=dev))):
+        ts = []
+        for i in range(20):
+            if stream is None:
+                prepared.launch(10**9, 42 + i, out)
+            else:
+                with torch.cuda.stream(stream):
+                    prepared.launch(10**9, 42 + i, out)
+            ts.append(mc._engine.last_kernel_ms())
+        print(f"prepared.launch on the {label}: kernel min {min(ts):.3f} median {sorted(ts)[10]:.3f} max {max(ts):.3f} ms")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "device":
+    device_path()
