@@ -137,6 +137,9 @@ typedef struct mcx_module_desc {
     int32_t walk;              /* MCMC only. MCX_WALK_INDEPENDENT (0, the reference: x' ~ q, shader_gen.rs:466-539),
                                 * MCX_WALK_RANDOM (1): x' = x + d, d ~ q, log alpha = log p(x') - log p(x) + log q(-d) - log q(d),
                                 * MCX_WALK_RANDOM_SYMMETRIC (2): same with the q terms dropped (caller guarantees q(d) = q(-d)).
+                                * MCX_WALK_ADAPTIVE (3): symmetric random walk x' = x + s d whose per-chain scale s adapts during
+                                * burn-in only (log s += t^-1/2 (accepted - target_accept) after step t, s = 1 at the start) and is
+                                * frozen for the sampling steps; one more result row holds the sum of the final scales.
                                 * Random-walk proposals outside the target table (log p <= -100) are always rejected.
                                 * The reference leaves this open ("For now, we use independent proposal", shader_gen.rs:514). */
     int32_t cell_tables;       /* 1: the caller guarantees every PDF / log-PDF table bound to this module has the
@@ -167,9 +170,10 @@ typedef struct mcx_module_desc {
 #define MCX_WALK_INDEPENDENT      0
 #define MCX_WALK_RANDOM           1
 #define MCX_WALK_RANDOM_SYMMETRIC 2
+#define MCX_WALK_ADAPTIVE         3
 
 /* Number of doubles a call with this module writes to sums_out / d_sums (<= 65), or a negative error:
- * integrate: k (2k with second_moments); MCMC: k + 1 (3k + 1 with second_moments). */
+ * integrate: k (2k with second_moments); MCMC: k + 1 (3k + 1 with second_moments), one more with MCX_WALK_ADAPTIVE. */
 int  mcx_result_rows(const mcx_module_desc* desc);
 
 /* user_src: HIP C++ text defining `__device__ float user_func_i(float x)` for i < k (and
@@ -247,13 +251,14 @@ typedef struct mcx_mcmc_params {
     const mcx_table* target_logpdf;    /* MCX_TABLE_LOGPDF, required */
     const mcx_table* proposal_logpdf;  /* MCX_TABLE_LOGPDF, required unless desc.q_sampler */
     float    x0;                 /* random-walk modules: chains start at x0 + d_0 (d_0 = the iter-0 draw); else ignored */
-    uint32_t reserved;           /* 0 */
+    float    target_accept;      /* MCX_WALK_ADAPTIVE: acceptance rate the step scale is tuned towards (0 < a < 1) */
 } mcx_mcmc_params;
 
 /* sums_out[0..k) = sum over this rank's chains and all sampling steps of f_k(x_t);
  * sums_out[k] = number of accepted steps (burn-in included); n_eff_out = padded chains * n_steps.
  * With desc.second_moments: [0..k) sums of f, [k..2k) sums of f^2, [2k] accepted steps,
- * [2k+1..3k+1) sums over chains of (chain mean of f_i)^2. */
+ * [2k+1..3k+1) sums over chains of (chain mean of f_i)^2. MCX_WALK_ADAPTIVE appends the sum of the chains' final
+ * step scales as the last row. */
 int mcx_mcmc(mcx_engine* e, mcx_module* m, const mcx_mcmc_params* p,
              double* sums_out, uint64_t* n_eff_out);
 int mcx_mcmc_device(mcx_engine* e, mcx_module* m, const mcx_mcmc_params* p,

@@ -50,7 +50,8 @@ class _McmcArgs(C.Structure):
                 ("param1", C.c_float), ("param2", C.c_float), ("table_size", C.c_uint32),
                 ("cdf_table", C.POINTER(C.c_float)), ("x_table", C.POINTER(C.c_float)),
                 ("target_logpdf", C.POINTER(C.c_float)), ("proposal_logpdf", C.POINTER(C.c_float)),
-                ("guard", C.c_int32), ("rng", C.c_int32), ("walk", C.c_int32), ("x0", C.c_float)]
+                ("guard", C.c_int32), ("rng", C.c_int32), ("walk", C.c_int32), ("x0", C.c_float),
+                ("target_accept", C.c_float)]
 
 
 _lib = None
@@ -222,9 +223,10 @@ def samples(dist_type, param1=0.0, param2=1.0, n_samples=1_000_000, seed=42, cdf
 
 def mcmc(fns, proposal_type, param1, param2, target_x, target_logpdf, proposal_x, proposal_logpdf,
          n_steps=1000, n_chains=256, n_burnin=100, seed=42, cdf_table=None, x_table=None,
-         target_threads=None, guard=0, trace_chains=0, rng=0, walk=0, x0=0.0):
+         target_threads=None, guard=0, trace_chains=0, rng=0, walk=0, x0=0.0, target_accept=0.44):
     """Restated K3. Returns dict(ref, sums (K+1, last = accepted steps), n_eff, trace, sumsq (K), chain_mean_sq (K)).
-    walk: 0 independent proposals (the reference), 1 / 2 libmcx's random-walk extensions (general / symmetric)."""
+    walk: 0 independent proposals (the reference), 1 / 2 / 3 libmcx's random-walk extensions (general / symmetric /
+    adaptive symmetric with step-scale tuning towards target_accept during burn-in)."""
     a = _McmcArgs()
     a.n_steps, a.n_chains, a.n_burnin = int(n_steps), int(n_chains), int(n_burnin)
     a.target_threads = int(target_threads or 0)
@@ -239,18 +241,19 @@ def mcmc(fns, proposal_type, param1, param2, target_x, target_logpdf, proposal_x
     a.target_logpdf, a.proposal_logpdf = _fp(tl), _fp(pl)
     a.guard = int(guard)
     a.rng = int(rng)
-    a.walk, a.x0 = int(walk), float(x0)
+    a.walk, a.x0, a.target_accept = int(walk), float(x0), float(target_accept)
     K = len(fns)
     ref = np.zeros(K, dtype=np.float32)
     sums = np.zeros(K + 1, dtype=np.float64)
-    diag = np.zeros(2 * K, dtype=np.float64)
+    diag = np.zeros(2 * K + 1, dtype=np.float64)
     n_eff = C.c_uint64(0)
     trace = np.zeros((trace_chains, n_steps), dtype=np.float32) if trace_chains else None
     rc = lib().orc_mcmc(C.byref(a), _fns(fns), K, _fp(ref), sums.ctypes.data_as(C.POINTER(C.c_double)),
                         C.byref(n_eff), _fp(trace), int(trace_chains), diag.ctypes.data_as(C.POINTER(C.c_double)))
     if rc:
         raise MemoryError("oracle allocation failed")
-    return dict(ref=ref, sums=sums, n_eff=int(n_eff.value), trace=trace, sumsq=diag[:K], chain_mean_sq=diag[K:])
+    return dict(ref=ref, sums=sums, n_eff=int(n_eff.value), trace=trace, sumsq=diag[:K], chain_mean_sq=diag[K:2 * K],
+                scale_sum=float(diag[2 * K]))
 
 
 def num_threads() -> int:

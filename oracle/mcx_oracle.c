@@ -365,6 +365,9 @@ typedef struct {
                                     * 2: random walk, symmetric q: log alpha = log p(x') - log p(x). Random-walk proposals with
                                     * log p(x') <= -100 (outside the target table) are always rejected. */
     float    x0;                   /* random walk: chains start at x0 + d_0 */
+    float    target_accept;        /* walk == 3 (libmcx's adaptive symmetric random walk): x' = x + s d with a per-chain
+                                    * scale s = exp(l), l = 0 at the start, l += t^-1/2 (accepted - target_accept) after
+                                    * burn-in step t, frozen for the sampling steps */
 } orc_mcmc_args;
 
 /* Philox stream of libmcx for K3: one call per two steps, (idx, it >> 1, 1, 0), key (seed, 'MCX1'). Step `it` takes
@@ -406,7 +409,8 @@ static float mcmc_sample_q(const orc_mcmc_args* a, orc_bm_state* bm, uint32_t id
 /* out_ref[k]: the reference's f32 result. out_sum64[k]: f64 sums over all padded chains and sampling
  * steps; out_sum64[K] = accepted steps (burn-in included). trace (optional): [chains_to_trace][n_steps]
  * chain states after each sampling step, for evaluating arbitrary functions in numpy. out_diag (optional,
- * 2K doubles): [0..K) sums of f^2, [K..2K) sums over chains of (f64 chain mean)^2 -- libmcx's batch-means rows. */
+ * 2K + 1 doubles): [0..K) sums of f^2, [K..2K) sums over chains of (f64 chain mean)^2 -- libmcx's batch-means rows --,
+ * [2K] the sum of the chains' final step scales (walk == 3; else the number of chains). */
 int orc_mcmc(const orc_mcmc_args* a, const orc_fn* fns, int K, float* out_ref, double* out_sum64,
              uint64_t* n_eff, float* trace, uint32_t chains_to_trace, double* out_diag) {
     uint32_t cfg[4];
@@ -415,7 +419,7 @@ int orc_mcmc(const orc_mcmc_args* a, const orc_fn* fns, int K, float* out_ref, d
     if (n_eff) *n_eff = (uint64_t)T * (uint64_t)a->n_steps;
     float* out = (float*)malloc((size_t)T * K * sizeof(float));
     double* s64 = (double*)calloc((size_t)T * (K + 1), sizeof(double));
-    double* d64 = (double*)calloc((size_t)T * 2 * K, sizeof(double));
+    double* d64 = (double*)calloc((size_t)T * (2 * K + 1), sizeof(double));
     if (!out || !s64 || !d64) { free(out); free(s64); free(d64); return -1; }
 #pragma omp parallel for schedule(static)
     for (int64_t t = 0; t < (int64_t)T; ++t) {
@@ -426,6 +430,7 @@ int orc_mcmc(const orc_mcmc_args* a, const orc_fn* fns, int K, float* out_ref, d
         if (a->walk) current_x += a->x0;
         float current_log_p = orc_table_lookup(a->target_logpdf, current_x, -100.0f);
         uint64_t accepted = 0;
+        float log_s = 0.0f, scale = 1.0f;
         float acc[64];
         double acc64[64], sq64[64];
         for (int k = 0; k < K; ++k) { acc[k] = 0.0f; acc64[k] = 0.0; sq64[k] = 0.0; }
@@ -434,7 +439,7 @@ int orc_mcmc(const orc_mcmc_args* a, const orc_fn* fns, int K, float* out_ref, d
             uint32_t accept_hash = 0u;
             float draw = a->rng == 1 ? mcmc_sample_q_philox(a, idx, it, &accept_hash)
                                      : mcmc_sample_q(a, &bm, idx, it + 1000000u);         /* shader_gen.rs:477-489 */
-            float proposal_x = a->walk ? current_x + draw : draw;
+            float proposal_x = a->walk == 3 ? fmaf(scale, draw, current_x) : (a->walk ? current_x + draw : draw);
             float proposal_log_p_target = orc_table_lookup(a->target_logpdf, proposal_x, -100.0f);
             float log_alpha;
             if (a->walk == 0) {
@@ -445,17 +450,22 @@ int orc_mcmc(const orc_mcmc_args* a, const orc_fn* fns, int K, float* out_ref, d
                 float lq_fwd = orc_table_lookup(a->proposal_logpdf, draw, -100.0f);
                 float lq_back = orc_table_lookup(a->proposal_logpdf, -draw, -100.0f);
                 log_alpha = proposal_log_p_target + lq_back - current_log_p - lq_fwd;
-            } else {
+            } else {                                   /* walk 2 and 3: symmetric increments */
                 log_alpha = proposal_log_p_target - current_log_p;
             }
             float u = a->rng == 1 ? u_from_hash(accept_hash)
                                   : orc_random_uniform(a->seed + 999999u, idx, it);    /* shader_gen.rs:529 */
+            const int was_inside = current_log_p > -100.0f;
             int take = logf(u) < log_alpha;
             if (a->walk && !(proposal_log_p_target > -100.0f)) take = 0;   /* outside the target table: density 0 */
             if (take) {
                 current_x = proposal_x;
                 current_log_p = proposal_log_p_target;
                 ++accepted;
+            }
+            if (a->walk == 3 && it <= a->n_burnin) {      /* no adaptation while the chain is outside the target table */
+                log_s = fmaf(was_inside ? 1.0f / sqrtf((float)it) : 0.0f, (take ? 1.0f : 0.0f) - a->target_accept, log_s);
+                scale = exp2f(log_s * 1.4426950408889634f);
             }
             if (it > a->n_burnin) {
                 for (int k = 0; k < K; ++k) {
@@ -474,14 +484,15 @@ int orc_mcmc(const orc_mcmc_args* a, const orc_fn* fns, int K, float* out_ref, d
         s64[(size_t)idx * (K + 1) + K] = (double)accepted;
         for (int k = 0; k < K; ++k) {
             double m = acc64[k] / (double)a->n_steps;
-            d64[(size_t)idx * 2 * K + k] = sq64[k];
-            d64[(size_t)idx * 2 * K + K + k] = m * m;
+            d64[(size_t)idx * (2 * K + 1) + k] = sq64[k];
+            d64[(size_t)idx * (2 * K + 1) + K + k] = m * m;
         }
+        d64[(size_t)idx * (2 * K + 1) + 2 * K] = (double)scale;
     }
     if (out_diag)
-        for (int k = 0; k < 2 * K; ++k) {
+        for (int k = 0; k < 2 * K + 1; ++k) {
             double s = 0.0;
-            for (uint32_t t = 0; t < T; ++t) s += d64[(size_t)t * 2 * K + k];
+            for (uint32_t t = 0; t < T; ++t) s += d64[(size_t)t * (2 * K + 1) + k];
             out_diag[k] = s;
         }
     for (int k = 0; k <= K; ++k) {

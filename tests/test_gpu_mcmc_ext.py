@@ -155,3 +155,36 @@ def test_unknown_proposal_kind(integrator):
     d = Distribution.normal(0, 1)
     with pytest.raises(ValueError, match="proposal_kind"):
         integrator.integrate_mcmc(F, d, d, proposal_kind="langevin")
+
+
+@pytest.mark.parametrize("case", ["normal_small", "normal_large", "uniform_philox"])
+def test_adaptive_random_walk_matches_oracle(case):
+    """proposal_kind="adaptive_random_walk": the per-chain step scale tuned during burn-in, same as the oracle's
+    restatement; acceptance of the sampling phase near the target; the mean final scale reported."""
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+
+    target = Distribution.normal(0.5, 1.0)
+    step, code, p1, p2, rng = {"normal_small": (Distribution.normal(0.0, 0.05), oracle.NORMAL, 0.0, 0.05, "pcg_ref"),
+                               "normal_large": (Distribution.normal(0.0, 25.0), oracle.NORMAL, 0.0, 25.0, "pcg_ref"),
+                               "uniform_philox": (Distribution.uniform(-0.3, 0.3), oracle.UNIFORM, -0.3, 0.3, "philox")}[case]
+    kw = dict(n_steps=1200, n_chains=512, n_burnin=1200, seed=9)
+    mc = MonteCarloIntegrator(rng=rng, std_error=True)
+    res = mc.integrate_mcmc(F, target, step, proposal_kind="adaptive_random_walk", initial_state=0.5, target_accept=0.4, **kw)
+    ref = _oracle(target, step, code, p1, p2, walk=3, x0=0.5, target_accept=0.4, rng=int(rng == "philox"), **kw)
+    want = ref["sums"][:2] / ref["n_eff"]
+    assert np.all(np.abs(res.values - want) < 6e-3), (res.values, want)
+    assert abs(res.meta["step_scale"] - ref["scale_sum"] / 512) < 0.02 * ref["scale_sum"] / 512
+    assert abs(res.values[0] - 0.5) < 0.05 and abs(res.values[1] - 1.25) < 0.1, res.values
+    # acceptance over burn-in + sampling is pulled towards the target from either side
+    assert 0.3 < res.meta["accept_rate"] < 0.55, res.meta["accept_rate"]
+    assert np.all(np.isfinite(res.meta["std_error"]))
+
+
+def test_adaptive_random_walk_validation(integrator):
+    from wgpu_montecarlo import Distribution
+
+    d = Distribution.normal(0, 1)
+    with pytest.raises(ValueError, match="symmetric"):
+        integrator.integrate_mcmc(F, d, Distribution.normal(0.3, 1.0), proposal_kind="adaptive_random_walk")
+    with pytest.raises(ValueError, match="target_accept"):
+        integrator.integrate_mcmc(F, d, d, proposal_kind="adaptive_random_walk", target_accept=1.5)

@@ -115,7 +115,9 @@ def test_result_rows_and_walk_validation():
     with pytest.raises(ValueError, match="walk"):
         rt.result_rows(rt.make_desc(rt.KIND_INTEGRATE, 2, rt.DIST_NORMAL, walk=1))
     with pytest.raises(ValueError, match="walk"):
-        rt.result_rows(rt.make_desc(rt.KIND_MCMC, 2, rt.DIST_NORMAL, walk=3))
+        rt.result_rows(rt.make_desc(rt.KIND_MCMC, 2, rt.DIST_NORMAL, walk=4))
+    assert rt.result_rows(rt.make_desc(rt.KIND_MCMC, 2, rt.DIST_NORMAL, walk=3)) == 4          # + the step-scale row
+    assert rt.result_rows(rt.make_desc(rt.KIND_MCMC, 2, rt.DIST_NORMAL, walk=3, second_moments=True)) == 8
 
 
 @pytest.mark.parametrize("walk", [1, 2])
@@ -128,3 +130,21 @@ def test_walk_modules_compile_for_gfx950(walk):
     text = rt.module_source(src, desc)
     assert f"#define MCX_WALK {walk}" in text and "#define MCX_NF 2" in text and "#define MCX_K 4" in text
     rt.precompile(src, desc)
+
+
+@pytest.mark.parametrize("s0", [0.05, 1.0, 30.0])
+def test_adaptive_walk_tunes_the_step_scale(s0):
+    """walk = 3: whatever the increments' own scale, the per-chain scale adapts during burn-in until the acceptance
+    rate of the sampling phase is near the target, and the moments of N(0,1) come out right."""
+    target = Distribution.normal(0.0, 1.0)
+    step = Distribution.normal(0.0, s0)
+    args = dict(n_steps=1500, n_chains=256, n_burnin=1500, seed=21, guard=1, walk=3, target_accept=0.44, trace_chains=256)
+    r = oracle.mcmc(FNS, oracle.NORMAL, 0.0, s0, *_tables(target, step), **args)
+    mean_scale = r["scale_sum"] / 256
+    # optimal proposal std for a unit normal target at 44 % acceptance is about 2.4: scale * s0 should land near it
+    assert 1.2 < mean_scale * s0 < 4.5, mean_scale * s0
+    tr = r["trace"]
+    moved = (tr[:, 1:] != tr[:, :-1]).mean()
+    assert abs(moved - 0.44) < 0.08, moved
+    m = r["sums"][:2] / r["n_eff"]
+    assert abs(m[0]) < 0.05 and abs(m[1] - 1.0) < 0.08, m

@@ -65,6 +65,8 @@ typedef struct McxMcmcArgs {
     float   x0;                 // random-walk start (chains start at x0 + first draw)
     float   param1;             // proposal min / mean / lambda
     float   param2;             // proposal max / std
+    float   target_accept;      // MCX_WALK 3: acceptance rate the per-chain step scale adapts towards during burn-in
+    mcx_u32 _pad0;
     McxTableDesc cdf;           // custom proposal sampling {cdf, x}
     McxTableDesc target_logpdf;   // {x, log p}
     McxTableDesc proposal_logpdf; // {x, log q}

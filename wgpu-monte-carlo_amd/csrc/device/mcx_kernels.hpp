@@ -434,7 +434,8 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 // =============================================================================================
 // K3: Metropolis-Hastings, one chain per thread. MCX_WALK 0: independent proposals x' ~ q (the reference);
 // 1: random walk x' = x + d, d ~ q, with the Hastings correction log q(-d) - log q(d); 2: random walk with a
-// symmetric q (no correction). MCX_SECOND_MOMENTS: accumulators also carry f^2, and every chain adds the
+// symmetric q (no correction); 3: symmetric random walk x' = x + s d whose per-chain scale s is tuned during burn-in
+// (log s += t^-1/2 (accepted - target) after step t) and frozen afterwards. MCX_SECOND_MOMENTS: accumulators also carry f^2, and every chain adds the
 // square of its own mean to rows MCX_K+1.. (batch means over chains -> standard error, effective sample size).
 // =============================================================================================
 #ifndef MCX_WALK
@@ -444,10 +445,11 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 #define MCX_SECOND_MOMENTS 0
 #endif
 #if MCX_SECOND_MOMENTS
-#define MCX_MCMC_ROWS (MCX_K + 1 + MCX_NF)
+#define MCX_MCMC_ROWS0 (MCX_K + 1 + MCX_NF)
 #else
-#define MCX_MCMC_ROWS (MCX_K + 1)
+#define MCX_MCMC_ROWS0 (MCX_K + 1)
 #endif
+#define MCX_MCMC_ROWS (MCX_MCMC_ROWS0 + (MCX_WALK == 3 ? 1 : 0))     // adaptive walk: + the sum of the final step scales
 #ifndef MCX_PROP_ITER_OFFSET
 #define MCX_PROP_ITER_OFFSET 1000000u      // shader_gen.rs:477-489
 #endif
@@ -558,11 +560,17 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #endif
     // Second half of a Metropolis-Hastings step (shader_gen.rs:527-537): accept test, state update, accumulation.
     // `it` is wave-uniform. prop_lq is used by the independent sampler only (it becomes the cached log q(current)).
+#if MCX_WALK == 3
+    float ad_log_s = 0.0f, ad_scale = 1.0f;      // per-chain step scale, adapted during burn-in only
+#endif
     auto mh_finish = [&](u32 it, float prop_x, float prop_lp, float prop_lq, float log_alpha, u32 ha) {
 #if MCX_PRECISE_SAMPLER
         float ln_u = logf(mcx_u01_closed(ha));
 #else
         float ln_u = fmaf(__builtin_amdgcn_logf((float)ha), 0x1.62e43p-1f, -32.0f * 0x1.62e43p-1f);   // h = 0 -> -inf: accept
+#endif
+#if MCX_WALK == 3
+        const bool was_inside = cur_lp > -100.0f;
 #endif
 #if MCX_WALK
         // a proposal outside the target table has density 0, not e^-100: without this a chain that starts outside
@@ -579,6 +587,15 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
         (void)prop_lq;
 #endif
         n_accept += (u64)__builtin_popcountll(__builtin_amdgcn_ballot_w64(take));
+#if MCX_WALK == 3
+        if (it <= a.n_burnin) {                  // wave-uniform; diminishing adaptation, none while sampling
+            // a chain that is still outside the target table rejects every proposal that does not land inside: that
+            // says nothing about the scale, and shrinking it there would strand the chain
+            const float g = was_inside ? __builtin_amdgcn_rsqf((float)it) : 0.0f;
+            ad_log_s = fmaf(g, (take ? 1.0f : 0.0f) - a.target_accept, ad_log_s);
+            ad_scale = __builtin_amdgcn_exp2f(ad_log_s * 1.4426950408889634f);
+        }
+#endif
         if (it > a.n_burnin) {                   // accumulate after every sampling step (shader_gen.rs:417-423)
             mcx_eval_all<1>(cur_x, 1.0f, acc);
             if (++since_flush == 2u * MCX_FLUSH) {
@@ -616,8 +633,12 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
         float lq_back = mcx_table_lookup(lq_tb, -draw, -100.0f);                   // q(x | x') = q(-d)
         mh_finish(it, prop_x, prop_lp, 0.0f, prop_lp + lq_back - cur_lp - lq_fwd, ha);
 #endif
-#else
+#elif MCX_WALK == 2
         const float prop_x = cur_x + draw;
+        float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
+        mh_finish(it, prop_x, prop_lp, 0.0f, prop_lp - cur_lp, ha);
+#else
+        const float prop_x = fmaf(ad_scale, draw, cur_x);
         float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
         mh_finish(it, prop_x, prop_lp, 0.0f, prop_lp - cur_lp, ha);
 #endif
@@ -680,6 +701,10 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #pragma unroll
         for (int k = 0; k < MCX_NF; ++k) { const double m = sum[k] * inv_steps; sum[MCX_K + 1 + k] = m * m; }
     }
+#endif
+
+#if MCX_WALK == 3
+    sum[MCX_MCMC_ROWS - 1] = active ? (double)ad_scale : 0.0;
 #endif
 
     mcx_block_reduce_store<MCX_MCMC_ROWS>(sum, a.partials);

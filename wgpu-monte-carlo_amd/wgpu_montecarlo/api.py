@@ -379,17 +379,23 @@ class MonteCarloIntegrator:
     def integrate_mcmc(self, functions: List[FunctionLike], target_distribution: Distribution,
                        proposal_distribution: Distribution, n_steps: int = 10_000, n_chains: int = 1024,
                        n_burnin: int = 1_000, seed: int = 42, proposal_kind: str = "independent",
-                       initial_state: float = 0.0) -> IntegrationResult:
+                       initial_state: float = 0.0, target_accept: float = 0.44) -> IntegrationResult:
         """E_p[f_k(X)] by Metropolis-Hastings, one chain per logical thread.
 
         proposal_kind="independent" (default) is the reference's sampler: x' ~ proposal_distribution
         (shader_gen.rs:466-539). proposal_kind="random_walk" (extension; the reference leaves it open at
         shader_gen.rs:514) draws the *increment* from proposal_distribution: x' = x + d, chains start at
         initial_state + d_0; the Hastings correction log q(-d) - log q(d) is applied unless the increment
-        distribution is symmetric about 0 (normal(0, s), uniform(-w, w)). With std_error=True the result carries
+        distribution is symmetric about 0 (normal(0, s), uniform(-w, w)). proposal_kind="adaptive_random_walk"
+        (symmetric increments only) additionally tunes a per-chain step scale during burn-in towards `target_accept`
+        (x' = x + s d; log s += t^-1/2 (accepted - target_accept) after burn-in step t; frozen while sampling) and
+        reports the mean final scale as meta["step_scale"]. With std_error=True the result carries
         meta["std_error"] (batch means over chains), meta["ess"] and meta["tau_int"] per function (K <= 16)."""
-        if proposal_kind not in ("independent", "random_walk"):
-            raise ValueError(f"Unknown proposal_kind: {proposal_kind!r} (expected 'independent' or 'random_walk')")
+        if proposal_kind not in ("independent", "random_walk", "adaptive_random_walk"):
+            raise ValueError(f"Unknown proposal_kind: {proposal_kind!r} (expected 'independent', 'random_walk' or "
+                             f"'adaptive_random_walk')")
+        if proposal_kind == "adaptive_random_walk" and not 0.0 < float(target_accept) < 1.0:
+            raise ValueError("target_accept must lie strictly between 0 and 1")
         if len(functions) == 0:
             raise ValueError("At least one function is required")
         if n_steps <= 0:
@@ -417,9 +423,13 @@ class MonteCarloIntegrator:
         cdf = self._cdf_table(proposal_distribution)
         lds_ok = self._lds_bytes(cdf, t_table, q_table) <= _LDS_TABLE_BUDGET
         walk = runtime.WALK_INDEPENDENT
-        if proposal_kind == "random_walk":
+        if proposal_kind != "independent":
             symmetric = (code == runtime.DIST_NORMAL and p1 == 0.0) or (code == runtime.DIST_UNIFORM and p1 == -p2)
             walk = runtime.WALK_RANDOM_SYMMETRIC if symmetric else runtime.WALK_RANDOM
+            if proposal_kind == "adaptive_random_walk":
+                if not symmetric:
+                    raise ValueError("adaptive_random_walk needs increments symmetric about 0: normal(0, s) or uniform(-w, w)")
+                walk = runtime.WALK_ADAPTIVE
         desc = runtime.make_desc(runtime.KIND_MCMC, len(functions), code, guard_endpoints=self._guard,
                                  precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng,
                                  unit_params=_unit_params(code, p1, p2), second_moments=self._std_error, walk=walk,
@@ -431,7 +441,7 @@ class MonteCarloIntegrator:
         values, n_eff = self._run(rows, lambda d_sums, stream: self._engine.mcmc(
             mod, n_steps, n_chains, n_burnin, seed, p1, p2, t_table, q_table,
             target_threads=self._target_threads, cdf=cdf, rank=rank, world=world, d_sums=d_sums, stream=stream,
-            x0=float(initial_state)))
+            x0=float(initial_state), target_accept=float(target_accept)))
         meta = self._meta(n_eff)
         total_chains = n_eff // n_steps
         # chains whose counters collide replay each other's random numbers with a time shift: the estimate stays
@@ -441,6 +451,8 @@ class MonteCarloIntegrator:
         row_accept = 2 * k if self._std_error else k
         meta["accept_rate"] = float(values[row_accept]) * n_eff / (float(total_chains) * (n_steps + n_burnin))
         meta["proposal_kind"] = proposal_kind
+        if walk == runtime.WALK_ADAPTIVE:
+            meta["step_scale"] = float(values[-1]) * n_eff / float(total_chains)      # mean final scale over the chains
         if self._std_error:
             # batch means with one batch per chain: chains are independent, so the spread of their means measures
             # the Monte-Carlo error whatever the autocorrelation inside a chain is

@@ -23,7 +23,7 @@ DIST_UNIFORM, DIST_NORMAL, DIST_EXPONENTIAL, DIST_CUSTOM = 0, 1, 2, 3
 TABLE_CDF, TABLE_PDF, TABLE_LOGPDF = 0, 1, 2
 KIND_INTEGRATE, KIND_MCMC = 0, 1
 RNG_PCG_REF, RNG_PHILOX = 0, 1
-WALK_INDEPENDENT, WALK_RANDOM, WALK_RANDOM_SYMMETRIC = 0, 1, 2
+WALK_INDEPENDENT, WALK_RANDOM, WALK_RANDOM_SYMMETRIC, WALK_ADAPTIVE = 0, 1, 2, 3
 RNG_CODES = {"pcg_ref": RNG_PCG_REF, "philox": RNG_PHILOX}
 
 E_INVALID, E_RUNTIME, E_COMPILE, E_NODEVICE = -1, -2, -3, -4
@@ -61,7 +61,7 @@ class McmcParams(C.Structure):
                 ("target_threads", C.c_int64), ("seed", C.c_uint32), ("param1", C.c_float),
                 ("param2", C.c_float), ("rank", C.c_uint32), ("world", C.c_uint32),
                 ("cdf", C.c_void_p), ("target_logpdf", C.c_void_p), ("proposal_logpdf", C.c_void_p),
-                ("x0", C.c_float), ("reserved", C.c_uint32)]
+                ("x0", C.c_float), ("target_accept", C.c_float)]
 
 
 # every symbol include/mcx.h declares (tests check that the library exports all of them)
@@ -434,12 +434,12 @@ class Engine:
     def mcmc(self, mod: Module, n_steps: int, n_chains: int, n_burnin: int, seed: int, param1: float,
              param2: float, target_logpdf: Table, proposal_logpdf: Table, target_threads: Optional[int] = None,
              cdf: Optional[Table] = None, rank: int = 0, world: int = 1, d_sums: Optional[int] = None,
-             stream: Optional[int] = None, x0: float = 0.0):
+             stream: Optional[int] = None, x0: float = 0.0, target_accept: float = 0.44):
         """Returns (sums float64[result_rows(desc)] (row k, or 2k with second moments = accepted steps) or None,
         n_eff)."""
         p = McmcParams(int(n_steps), int(n_chains), int(n_burnin), int(target_threads or 0),
                        int(seed) & 0xFFFFFFFF, float(param1), float(param2), int(rank), int(world),
-                       self._ptr(cdf), self._ptr(target_logpdf), self._ptr(proposal_logpdf), float(x0), 0)
+                       self._ptr(cdf), self._ptr(target_logpdf), self._ptr(proposal_logpdf), float(x0), float(target_accept))
         n_eff = C.c_uint64(0)
         if d_sums is not None:
             check(load().mcx_mcmc_device(self._h, mod._h, C.byref(p), C.c_void_p(d_sums),
@@ -491,12 +491,12 @@ def integrate_multi(shards, n_samples: int, seed: int, param1: float, param2: fl
 
 
 def mcmc_multi(shards, n_steps: int, n_chains: int, n_burnin: int, seed: int, param1: float, param2: float,
-               target_threads: Optional[int] = None, x0: float = 0.0):
+               target_threads: Optional[int] = None, x0: float = 0.0, target_accept: float = 0.44):
     """Chain-sharded MH over len(shards) engines. tables-dict keys: cdf, target_logpdf, proposal_logpdf."""
     def make(r, n, eng, tb):
         return McmcParams(int(n_steps), int(n_chains), int(n_burnin), int(target_threads or 0), int(seed) & 0xFFFFFFFF,
                           float(param1), float(param2), r, n, Engine._ptr(tb.get("cdf")), Engine._ptr(tb.get("target_logpdf")),
-                          Engine._ptr(tb.get("proposal_logpdf")), float(x0), 0)
+                          Engine._ptr(tb.get("proposal_logpdf")), float(x0), float(target_accept))
     return _multi("mcx_mcmc_multi", shards, make, McmcParams)
 
 
