@@ -119,13 +119,16 @@ def main():
         sig = np.sqrt(np.array([5.0, 18.0]) * tau / res.meta["n_eff"])
         report("C4 MCMC K=2 bimodal target, N(0,2) proposal, 1048576 chains x (1000 + 10000) steps", res, [0, 5], sig,
                wall, steps, "MH steps/s")
-    if "C4RW" in only or "C4D" in only:
+    if "C4RW" in only or "C4D" in only or "C4A" in only:
         # extensions either side of C4: random-walk proposals and the batch-means diagnostics, at C4's size
         chains = int(1_048_576 * args.scale)
         target = Distribution.from_pdf(bimodal, support=(-10, 10))
         variants = []
         if "C4RW" in only:
             variants.append(("C4RW random-walk MH, N(0,2.5) increments", MonteCarloIntegrator(rng=args.rng), "random_walk", Distribution.normal(0.0, 2.5)))
+        if "C4A" in only:
+            variants.append(("C4A adaptive random-walk MH, N(0,0.2) increments, target acceptance 0.44", MonteCarloIntegrator(rng=args.rng, std_error=True),
+                             "adaptive_random_walk", Distribution.normal(0.0, 0.2)))
         if "C4D" in only:
             variants.append(("C4D independent MH + batch-means rows (std_error=True)", MonteCarloIntegrator(std_error=True, rng=args.rng),
                              "independent", Distribution.normal(0.0, 2.0)))
@@ -140,6 +143,8 @@ def main():
                 tau = 12.0                                   # measured by the C4D line below for these increments
                 se = np.sqrt(np.array([5.0, 18.0]) * tau / res.meta["n_eff"])
             report(name + f", {chains} chains x (1000 + 10000) steps", res, [0, 5], se, wall, steps, "MH steps/s")
+            if "step_scale" in res.meta:
+                out[-1]["step_scale"] = res.meta["step_scale"]
             if "tau_int" in res.meta:
                 out[-1]["tau_int"] = res.meta["tau_int"].tolist()
                 out[-1]["ess"] = res.meta["ess"].tolist()
