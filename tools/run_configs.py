@@ -148,7 +148,8 @@ def main():
             if "tau_int" in res.meta:
                 out[-1]["tau_int"] = res.meta["tau_int"].tolist()
                 out[-1]["ess"] = res.meta["ess"].tolist()
-                print(json.dumps(dict(config=name, tau_int=out[-1]["tau_int"], ess=out[-1]["ess"])), flush=True)
+                print(json.dumps(dict(config=name, tau_int=out[-1]["tau_int"], ess=out[-1]["ess"],
+                                      step_scale=out[-1].get("step_scale"))), flush=True)
     if not only or "C5" in only:
         n = int(1e10 * args.scale)
         fns = [lambda x, k=k: x**k for k in range(1, 33)]      # bound defaults -> constants -> shared multiply chain
