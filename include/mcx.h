@@ -101,6 +101,9 @@ int  mcx_engine_device(const mcx_engine* e);
 float mcx_engine_last_kernel_ms(mcx_engine* e);
 /* Launch geometry of the last call: physical workgroups, threads per workgroup, dynamic LDS bytes. */
 int  mcx_engine_last_launch(mcx_engine* e, uint32_t* n_blocks, uint32_t* block, uint32_t* lds_bytes);
+/* Main-kernel launches the last call was split into (1 unless the call exceeded the per-launch work bound of
+ * ~1e11 samples / chain-steps, MCX_MAX_LAUNCH_UNITS; the reference always issues one dispatch, src/engine.rs:468-525). */
+uint32_t mcx_engine_last_launch_count(const mcx_engine* e);
 /* Tuning knob: physical threads a launch aims for (default 256 CUs x 2048 x 2). */
 int  mcx_engine_set_target_threads(mcx_engine* e, uint32_t physical_threads);
 
@@ -185,7 +188,14 @@ int  mcx_module_precompile(const char* user_src, const mcx_module_desc* desc, in
 int  mcx_module_source(const char* user_src, const mcx_module_desc* desc, char** out_text);
 void mcx_free(void* p);
 void mcx_module_release(mcx_module* m);
-/* Where code objects are cached (default: <dir of libmcx.so>/jit_cache, override MCX_CACHE_DIR). */
+/* Static LDS bytes of the module's main kernel (its cross-wave reduction scratch), read from the code object. */
+uint32_t mcx_module_static_lds(const mcx_module* m);
+/* LDS bytes a module built from `desc` leaves for staged tables: 160 KiB per CU minus (an upper bound of) the static
+ * scratch its kernel declares. A call whose tables (sum of mcx_table_lds_bytes) exceed it must build the module with
+ * tables_lds = 0; launches check the exact figure. 0 for an invalid desc. */
+uint32_t mcx_lds_table_budget(const mcx_module_desc* desc);
+/* Where code objects are cached (default: <dir of libmcx.so>/jit_cache, override MCX_CACHE_DIR). The in-memory copy
+ * is an LRU of MCX_CODE_CACHE_ENTRIES (default 256) code objects. */
 const char* mcx_cache_dir(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -265,17 +275,52 @@ int mcx_mcmc_device(mcx_engine* e, mcx_module* m, const mcx_mcmc_params* p,
                     void* d_sums, void* stream, uint64_t* n_eff_out);
 
 /* ------------------------------------------------------------------------------------------
- * One host thread, several devices (no torch, no RCCL): the shards params[r] (rank = r, world = n) are enqueued on
- * engines[r] without waiting, then the n results of mcx_result_rows doubles each are read back and added on the
- * host in rank order. The reference is single-device (src/engine.rs:91-131); this is the C-level equivalent of the
- * one-process-per-GPU path the Python layer runs over torch.distributed. modules[r] must have been built on
- * engines[r] from the same source and desc; tables in params[r] belong to engines[r]. Several engines may share
- * a device (how the tests exercise it on one GPU).
+ * One host thread, several devices. The reference is single-device (ComputeEngine::new picks one adapter,
+ * src/engine.rs:91-131); this is the C-level equivalent of the one-process-per-GPU path the Python layer runs over
+ * torch.distributed. The shards params[r] (rank = r, world = n) are enqueued on engines[r] without waiting in
+ * between. modules[r] must have been built on engines[r] from the same source and desc; tables in params[r] belong
+ * to engines[r].
+ *
+ * mcx_*_multi (no RCCL): the n results of mcx_result_rows doubles each are copied back (all copies in flight, then
+ * one wait per device) and added on the host in rank order. Several engines may share a device (how the tests
+ * exercise it on one GPU).
+ *
+ * mcx_*_comm (RCCL over xGMI): mcx_comm_create runs ncclCommInitAll over the engines' devices (one engine per
+ * distinct device); a call ends with ONE grouped ncclAllReduce (sum of mcx_result_rows doubles, in place in each
+ * engine's result buffer, on each engine's stream) and one copy of K doubles from rank 0. librccl is bound at run
+ * time like the HIP runtime (the copy already mapped in the process, else MCX_RCCL, else the system's).
  * ------------------------------------------------------------------------------------------ */
 int mcx_integrate_multi(mcx_engine* const* engines, mcx_module* const* modules, const mcx_integrate_params* const* params,
                         int n, double* sums_out, uint64_t* n_eff_out);
 int mcx_mcmc_multi(mcx_engine* const* engines, mcx_module* const* modules, const mcx_mcmc_params* const* params,
                    int n, double* sums_out, uint64_t* n_eff_out);
+
+
+/* ------------------------------------------------------------------------------------------
+ * Self-test: the integer side of the random streams computed on the GPU by the device functions the kernels use,
+ * returned raw for bit-exact comparison (tests/test_gpu_kat.py). For each of the n triples (seed, idx, iter):
+ * combined = seed + idx*7199369 + iter*15485863 and hash = pcg_hash(combined) (src/distribution.rs:62-73); stepped =
+ * the same hash reached by stepping the LCG state with adds as the hot loops do; angle = the hash word that feeds the
+ * Box-Muller angle (hash without its final xorshift); u = float(hash) * 2^-32. For each of the n_philox
+ * (counter[4], key[2]) pairs: the Philox4x32-10 block (Random123).
+ * ------------------------------------------------------------------------------------------ */
+int mcx_selftest_streams(mcx_engine* e, uint32_t n, const uint32_t* seed_idx_iter, uint32_t* combined_out,
+                         uint32_t* hash_out, uint32_t* stepped_out, uint32_t* angle_out, float* u_out,
+                         uint32_t n_philox, const uint32_t* counters, const uint32_t* keys, uint32_t* philox_out);
+/* Work bound of one main-kernel launch in samples / chain-steps (0 restores the default, ~1e11 or
+ * MCX_MAX_LAUNCH_UNITS): larger calls are split into several launches folded together (process-wide). */
+void mcx_set_max_launch_units(uint64_t units);
+
+typedef struct mcx_comm mcx_comm;
+const char* mcx_rccl_library(void);                 /* which librccl was bound ("" if none could be) */
+int  mcx_comm_create(mcx_engine* const* engines, int n, mcx_comm** out);
+void mcx_comm_destroy(mcx_comm* c);
+int  mcx_comm_size(const mcx_comm* c);
+/* modules[r] / params[r] belong to the r-th engine the communicator was created with (rank = r, world = size). */
+int mcx_integrate_comm(mcx_comm* c, mcx_module* const* modules, const mcx_integrate_params* const* params,
+                       double* sums_out, uint64_t* n_eff_out);
+int mcx_mcmc_comm(mcx_comm* c, mcx_module* const* modules, const mcx_mcmc_params* const* params,
+                  double* sums_out, uint64_t* n_eff_out);
 
 #ifdef __cplusplus
 }

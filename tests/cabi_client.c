@@ -28,7 +28,8 @@ int main(int argc, char** argv) {
     LOAD(mcx_version) LOAD(mcx_last_error) LOAD(mcx_dispatch_config) LOAD(mcx_mcmc_dispatch_config)
     LOAD(mcx_shard_integrate) LOAD(mcx_device_count) LOAD(mcx_engine_create) LOAD(mcx_engine_destroy)
     LOAD(mcx_module_build) LOAD(mcx_module_release) LOAD(mcx_integrate) LOAD(mcx_engine_last_kernel_ms)
-    LOAD(mcx_hip_runtime)
+    LOAD(mcx_hip_runtime) LOAD(mcx_comm_create) LOAD(mcx_comm_destroy) LOAD(mcx_comm_size) LOAD(mcx_integrate_comm)
+    LOAD(mcx_rccl_library) LOAD(mcx_lds_table_budget) LOAD(mcx_module_static_lds) LOAD(mcx_engine_last_launch_count)
 
     printf("OK version %s\n", p_mcx_version());
     mcx_dispatch d;
@@ -59,6 +60,25 @@ int main(int argc, char** argv) {
            tail, p_mcx_engine_last_kernel_ms(e));
     if (n_eff != 65536ull * 1526ull) return 1;
     if (fabs(mean) > 5e-4 || fabs(second - 1.0) > 1e-3 || fabs(tail - 0.158655) > 3e-4) return 1;
+    if (p_mcx_engine_last_launch_count(e) != 1u) return 1;
+    if (p_mcx_lds_table_budget(&desc) + p_mcx_module_static_lds(m) > 160u * 1024u || p_mcx_lds_table_budget(&desc) < 150u * 1024u) return 1;
+    /* single-process RCCL path: a communicator over this process's engines (here: the one GPU of the box); the call
+     * ends with ncclAllReduce(K doubles) on the engine's stream instead of a host-side sum */
+    {
+        mcx_comm* c = NULL;
+        mcx_engine* engines[1] = {e};
+        if (p_mcx_comm_create(engines, 1, &c)) { fprintf(stderr, "comm: %s\n", p_mcx_last_error()); return 1; }
+        if (p_mcx_comm_size(c) != 1) return 1;
+        mcx_module* mods[1] = {m};
+        const mcx_integrate_params* pp[1] = {&p};
+        double csums[3]; uint64_t cn = 0;
+        if (p_mcx_integrate_comm(c, mods, pp, csums, &cn)) { fprintf(stderr, "integrate_comm: %s\n", p_mcx_last_error()); return 1; }
+        if (cn != n_eff || csums[0] != sums[0] || csums[1] != sums[1] || csums[2] != sums[2]) {
+            fprintf(stderr, "comm sums differ: %.17g %.17g\n", csums[0], sums[0]); return 1;
+        }
+        p_mcx_comm_destroy(c);
+        printf("OK rccl communicator (1 rank) on %s: same sums\n", p_mcx_rccl_library());
+    }
     desc.k = 0;                                                     /* src/lib.rs:61-65 */
     mcx_module* bad = NULL;
     if (p_mcx_module_build(e, USER_SRC, &desc, &bad) != MCX_E_INVALID || !strstr(p_mcx_last_error(), "At least one function")) return 1;

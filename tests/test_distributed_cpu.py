@@ -34,7 +34,8 @@ def _worker(rank, world, port, n_samples, dist_code, out_dir):
     from wgpu_montecarlo import distributed
     from wgpu_montecarlo import runtime as rt
 
-    group = distributed.default_group()
+    assert distributed.default_group() is None           # sharding is opt-in: nothing is picked up implicitly
+    group = distributed.resolve_group("world")
     assert group is not None and (group.rank, group.world, group.backend) == (rank, world, "gloo")
     d = rt.dispatch_config(n_samples)
     shard = rt.shard_integrate(d, dist_code, group.rank, group.world)

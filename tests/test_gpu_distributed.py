@@ -49,7 +49,8 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from wgpu_montecarlo import Distribution, MonteCarloIntegrator
 
-    mc = MonteCarloIntegrator(device=0)                     # picks up the world group: every call is sharded
+    assert MonteCarloIntegrator(device=0)._rank_world() == (0, 1)      # sharding is opt-in
+    mc = MonteCarloIntegrator(device=0, process_group="world")         # every call is sharded over the world group
     assert mc._rank_world() == (rank, world)
     res = _calls(mc, Distribution)
     np.savez(Path(out_dir) / f"rank{rank}.npz", **res)

@@ -1,0 +1,186 @@
+"""Runtime corners of libmcx on the GPU: the LDS budget next to a kernel's static scratch, chunked launches for very
+long calls, the single-process RCCL communicator, module eviction while launches are in flight."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lds_budget_accounts_for_static_scratch(integrator):
+    """MCMC with std_error=True and K = 16 declares 16 waves x 49 rows x 8 B = 6.1 KiB of static reduction scratch
+    (block 1024): a ~155 KiB target table used to pass the host check (<= 156 KiB) and then fail at
+    hipModuleLaunchKernel. Now the budget is 160 KiB minus the module's static LDS: the API falls back to
+    tables_lds = 0 when the tables do not fit, and a C caller gets MCX_E_INVALID naming the budget, not a HIP error."""
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+    from wgpu_montecarlo import runtime as rt
+
+    desc = rt.make_desc(rt.KIND_MCMC, 16, rt.DIST_NORMAL, second_moments=True, cell_tables=True, q_sampler=True)
+    budget = rt.lds_table_budget(desc)
+    assert 150 * 1024 <= budget <= 160 * 1024 - 16 * 49 * 8
+    assert rt.lds_table_budget(rt.make_desc(rt.KIND_INTEGRATE, 4, rt.DIST_CUSTOM)) > budget    # less scratch, more room
+
+    mc = MonteCarloIntegrator(std_error=True)
+    mc._engine = rt.Engine(0)                                     # own engine: its table cache is dropped at the end
+    try:
+        fns = [lambda x, k=k: x**k for k in range(1, 17)]
+        pdf = lambda x: np.exp(-0.5 * x * x)
+        proposal = Distribution.normal(0.0, 1.5)                  # log q from the sampler's deviate: only the target table is staged
+        fits = Distribution.from_pdf(pdf, support=(-8.0, 8.0), table_size=budget // 8 - 64)
+        res = mc.integrate_mcmc(fns, fits, proposal, n_steps=60, n_chains=1024, n_burnin=10, seed=3)
+        assert np.all(np.isfinite(res.values))
+        assert budget - 1024 < res.meta["lds_bytes"] <= budget    # staged, right up to the budget
+        # a table inside the old 156 KiB limit but beyond what the static scratch leaves: must fall back, not fail
+        big = Distribution.from_pdf(pdf, support=(-8.0, 8.0), table_size=(155 * 1024) // 8)
+        res_big = mc.integrate_mcmc(fns, big, proposal, n_steps=60, n_chains=1024, n_burnin=10, seed=3)
+        assert np.all(np.isfinite(res_big.values)) and res_big.meta["lds_bytes"] == 0
+        assert np.allclose(res_big.values[:2], res.values[:2], atol=0.05)        # same chains, finer table of the same density
+        # the C-level contract: forcing the staged build for that table is refused with a clear message
+        tx, tl = big.get_log_pdf_table()
+        tb = mc._engine.cached_table(rt.TABLE_LOGPDF, tx, tl)
+        assert budget < tb.lds_bytes <= 156 * 1024
+        from wgpu_montecarlo.api import functions_to_hip
+
+        forced = rt.make_desc(rt.KIND_MCMC, 16, rt.DIST_NORMAL, second_moments=True, cell_tables=tb.has_cells, q_sampler=True)
+        mod = mc._engine.module(functions_to_hip(fns), forced)
+        with pytest.raises(ValueError, match="do not fit in LDS"):
+            mc._engine.mcmc(mod, 60, 1024, 10, 3, 0.0, 1.5, tb, None)
+    finally:
+        mc._engine.close()
+
+
+def test_static_lds_estimate_covers_the_code_objects(integrator):
+    """mcx_lds_table_budget reserves an upper bound of the static LDS; the launch check uses the code object's real
+    figure. The bound must never be below the real one (else a call the API staged would fail at launch)."""
+    from wgpu_montecarlo import runtime as rt
+    from wgpu_montecarlo.api import functions_to_hip
+
+    eng = integrator._engine
+    for kind, k, kw in [(rt.KIND_INTEGRATE, 4, dict(dist_type=rt.DIST_CUSTOM)), (rt.KIND_INTEGRATE, 32, dict(dist_type=rt.DIST_CUSTOM)),
+                        (rt.KIND_INTEGRATE, 32, dict(dist_type=rt.DIST_CUSTOM, second_moments=True)),
+                        (rt.KIND_INTEGRATE, 64, dict(dist_type=rt.DIST_CUSTOM)),
+                        (rt.KIND_MCMC, 2, dict(dist_type=rt.DIST_NORMAL)), (rt.KIND_MCMC, 16, dict(dist_type=rt.DIST_NORMAL, second_moments=True)),
+                        (rt.KIND_MCMC, 16, dict(dist_type=rt.DIST_NORMAL, second_moments=True, walk=rt.WALK_ADAPTIVE))]:
+        desc = rt.make_desc(kind, k, kw.pop("dist_type"), **kw)
+        src = functions_to_hip([lambda x, j=j: x**j for j in range(1, k + 1)])
+        mod = eng.module(src, desc)
+        reserved = 160 * 1024 - rt.lds_table_budget(desc)
+        assert 0 < mod.static_lds <= reserved, (kind, k, kw, mod.static_lds, reserved)
+
+
+def test_long_calls_are_split_into_several_launches(integrator):
+    """Calls above the per-launch work bound become several launches on one stream writing disjoint partial records,
+    folded once: same samples, same sums (up to summation order), launch count reported."""
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo import runtime as rt
+
+    fns = [lambda x: x, lambda x: x**2, lambda x: x**3]
+    n = 50_000_011
+    whole = integrator.integrate(fns, Distribution.normal(0.5, 1.5), n_samples=n, seed=9)
+    whole_beta = integrator.integrate(fns, Distribution.beta(2.0, 5.0), n_samples=n, seed=9)
+    target = Distribution.from_pdf(lambda x: np.exp(-0.5 * x * x), support=(-8.0, 8.0))
+    whole_mc = integrator.integrate_mcmc(fns[:2], target, Distribution.normal(0.0, 1.5), n_steps=200, n_chains=5000, n_burnin=20, seed=4)
+    assert whole.meta["n_eff"] > n and integrator._engine.last_launch()["launches"] == 1
+    try:
+        rt.set_max_launch_units(7_000_000)                         # -> 8 launches of the 5e7-sample calls
+        split = integrator.integrate(fns, Distribution.normal(0.5, 1.5), n_samples=n, seed=9)
+        launches = integrator._engine.last_launch()["launches"]
+        split_beta = integrator.integrate(fns, Distribution.beta(2.0, 5.0), n_samples=n, seed=9)
+        launches_beta = integrator._engine.last_launch()["launches"]
+        rt.set_max_launch_units(200_000)                           # 5120 padded chains x 220 steps = 1.1e6 chain-steps
+        split_mc = integrator.integrate_mcmc(fns[:2], target, Distribution.normal(0.0, 1.5), n_steps=200, n_chains=5000,
+                                             n_burnin=20, seed=4)
+        launches_mc = integrator._engine.last_launch()["launches"]
+    finally:
+        rt.set_max_launch_units(0)
+    assert launches == 8 and launches_beta == 8 and launches_mc >= 5
+    assert split.meta["n_eff"] == whole.meta["n_eff"]
+    assert np.allclose(split.values, whole.values, rtol=1e-10, atol=1e-10)
+    assert np.allclose(split_beta.values, whole_beta.values, rtol=1e-10, atol=1e-12)
+    assert np.allclose(split_mc.values, whole_mc.values, rtol=1e-10, atol=1e-12)       # chains are independent of the cut
+    assert split_mc.meta["accept_rate"] == pytest.approx(whole_mc.meta["accept_rate"], abs=1e-12)
+    # ... and the split sums agree with the oracle like any other launch
+    ref = oracle.integrate([(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2), (oracle.FN_POW, 3)], oracle.NORMAL, 0.5, 1.5,
+                           n_samples=n, seed=9, guard=1)
+    want = ref["sums"] / ref["n_eff"]
+    assert np.all(np.abs(split.values - want) < 2e-5 + 2e-5 * np.abs(want))
+
+
+def test_rccl_communicator_single_process(integrator):
+    """mcx_comm_*: ncclCommInitAll over this process's engines (one GPU on the test box, RCCL refuses duplicate
+    devices) + a grouped ncclAllReduce of the K doubles on the engine's stream instead of the host-side sum. With one
+    rank the collective is the identity: the sums must be bit-identical to the plain call, for K1 and K3."""
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo import runtime as rt
+    from wgpu_montecarlo.api import functions_to_hip
+
+    fns = [lambda x: x, lambda x: x**2, lambda x: x**3]
+    src = functions_to_hip(fns)
+    eng = rt.Engine(0)
+    comm = None
+    try:
+        comm = rt.Comm([eng])
+        assert comm.size == 1 and "rccl" in rt.rccl_library().lower()
+        desc = rt.make_desc(rt.KIND_INTEGRATE, 3, rt.DIST_NORMAL)
+        mod = eng.module(src, desc)
+        sums, n_eff = comm.integrate([(eng, mod, {})], 30_000_001, 11, 0.25, 2.0)
+        whole, n_eff1 = eng.integrate(mod, 30_000_001, 11, 0.25, 2.0)
+        assert n_eff == n_eff1 and np.array_equal(sums, whole)
+        for _ in range(3):                                          # the communicator is reusable
+            again, _ = comm.integrate([(eng, mod, {})], 30_000_001, 11, 0.25, 2.0)
+            assert np.array_equal(again, whole)
+        target = Distribution.normal(0.3, 1.0)
+        tx, tl = target.get_log_pdf_table()
+        desc3 = rt.make_desc(rt.KIND_MCMC, 3, rt.DIST_NORMAL, q_sampler=True, cell_tables=True)
+        mod3 = eng.module(src, desc3)
+        tb = dict(target_logpdf=eng.cached_table(rt.TABLE_LOGPDF, tx, tl))
+        sums3, _ = comm.mcmc([(eng, mod3, tb)], 300, 2000, 40, 5, 0.0, 2.0)
+        whole3, _ = eng.mcmc(mod3, 300, 2000, 40, 5, 0.0, 2.0, tb["target_logpdf"], None)
+        assert np.array_equal(sums3, whole3)
+        other = rt.Engine(0)
+        try:
+            with pytest.raises(ValueError, match="distinct device"):
+                rt.Comm([eng, other])
+        finally:
+            other.close()
+    finally:
+        if comm is not None:
+            comm.close()
+        eng.close()
+
+
+def test_module_eviction_waits_for_launches_in_flight():
+    """Engine.module() keeps the MAX_MODULES most recently used modules; an evicted module is unloaded only after its
+    last launch has finished (mcx_module_release waits on the module's last-use event). Here: a launch on a torch
+    stream is still running when its module is evicted and released."""
+    import torch
+
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+    from wgpu_montecarlo import runtime as rt
+
+    eng = rt.Engine(0)
+    old_max = rt.Engine.MAX_MODULES
+    rt.Engine.MAX_MODULES = 2
+    try:
+        mc = MonteCarloIntegrator()
+        mc._engine = eng
+        out = torch.zeros(3, 2, dtype=torch.float64, device="cuda")
+        want = []
+        stream = torch.cuda.Stream()
+        for i, c in enumerate((1.0, 2.0, 3.0)):
+            fns = [lambda x, c=c: c * x * x, lambda x, c=c: x + c]
+            prepared = mc.prepare_integrate(fns, Distribution.normal(0.0, 1.0))
+            with torch.cuda.stream(stream):
+                n_eff = prepared.launch(400_000_000, 5, out[i])       # ~0.2 ms each, queued back to back
+            del prepared                                              # the cache holds the only other reference
+            want.append([c, c])
+        assert len(eng._modules) == 2                                 # the first module was evicted while queued / running
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        got = out.cpu().numpy() / float(n_eff)
+        assert np.allclose(got, want, atol=2e-3), got
+    finally:
+        rt.Engine.MAX_MODULES = old_max
+        eng.close()

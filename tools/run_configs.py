@@ -6,7 +6,6 @@ one JSON line per config: values, truth, |err| vs 3 sigma, kernel time, samples 
 """
 import argparse
 import json
-import math
 import sys
 import time
 from pathlib import Path
@@ -19,29 +18,10 @@ sys.path.insert(0, str(ROOT / "wgpu-monte-carlo_amd"))
 from wgpu_montecarlo import Distribution, MonteCarloIntegrator  # noqa: E402
 
 
-def bimodal(x):
-    return 0.5 * (math.exp(-0.5 * (x - 2) ** 2) + math.exp(-0.5 * (x + 2) ** 2))
+sys.path.insert(0, str(ROOT / "tools"))
+import baseline_configs as bc  # noqa: E402
 
-
-def table_moments(xs, ps, qpdf, kmax):
-    """mu_k = integral x^k p~(x) dx for the piecewise-linear interpolant p~, and the IS variance
-    integral (x^k p~/q)^2 q dx - mu_k^2, by 4-point Gauss-Legendre on each table cell (+ fine sub-cells)."""
-    gx, gw = np.polynomial.legendre.leggauss(4)
-    sub = 8
-    mus, variances = [], []
-    edges = np.concatenate([np.linspace(xs[i], xs[i + 1], sub + 1)[:-1] for i in range(len(xs) - 1)] + [[xs[-1]]])
-    a, b = edges[:-1], edges[1:]
-    mid, half = (a + b) / 2, (b - a) / 2
-    pts = mid[:, None] + half[:, None] * gx[None, :]
-    w = half[:, None] * gw[None, :]
-    dens = np.interp(pts, xs, ps)
-    q = qpdf(pts)
-    for k in range(1, kmax + 1):
-        mu = float((pts**k * dens * w).sum())
-        second = float(((pts**k * dens) ** 2 / q * w).sum())
-        mus.append(mu)
-        variances.append(second - mu * mu)
-    return np.array(mus), np.array(variances)
+bimodal = bc.bimodal
 
 
 def timed(fn, repeat):
@@ -73,7 +53,7 @@ def main():
     f4 = lambda x: x**4
     out = []
 
-    def report(name, res, truth, sigma, wall, units, unit_name):
+    def report(name, res, truth, sigma, wall, units, unit_name, cfg=None):
         err = np.abs(res.values - truth)
         line = dict(config=name, values=res.values.tolist(), truth=np.asarray(truth).tolist(),
                     abs_err=err.tolist(), three_sigma=(3 * np.asarray(sigma)).tolist() if sigma is not None else None,
@@ -83,42 +63,23 @@ def main():
                     throughput_kernel=units / (res.meta["kernel_ms"] * 1e-3), throughput_call=units / wall, unit=unit_name)
         if "accept_rate" in res.meta:
             line["accept_rate"] = res.meta["accept_rate"]
+        if cfg in bc.OPS_PER_UNIT:
+            # algorithmic lane-ops per unit (derivation: tools/baseline_configs.py) against the VALU peak
+            achieved = units * bc.OPS_PER_UNIT[cfg] / (res.meta["kernel_ms"] * 1e-3)
+            line["roofline"] = dict(bound="valu", achieved=achieved / 1e12, peak=bc.VALU_PEAK_LANEOPS / 1e12, unit="Tlane-op/s",
+                                    frac=achieved / bc.VALU_PEAK_LANEOPS, ops_per_unit=bc.OPS_PER_UNIT[cfg],
+                                    kernel_ms=res.meta["kernel_ms"], kernel_ms_method="HIP events around the main kernel, best of the repeats")
         out.append(line)
         print(json.dumps(line), flush=True)
 
-    if not only or "C1" in only:
-        res, wall = timed(lambda: integ.integrate([f1, f2], Distribution.normal(0.0, 1.0), n_samples=1_000_000), args.repeat)
-        report("C1 integrate K=2 N(0,1) n=1e6", res, [0, 1], np.sqrt(np.array([1, 2]) / res.meta["n_eff"]), wall,
-               res.meta["n_eff"], "samples/s")
-    if not only or "C2" in only:
-        n = int(1e9 * args.scale)
-        res, wall = timed(lambda: integ.integrate([f1, f2, f3, f4], Distribution.normal(0.0, 1.0), n_samples=n), args.repeat)
-        report("C2 integrate K=4 N(0,1) n=1e9", res, [0, 1, 0, 3], np.sqrt(np.array([1, 2, 15, 96]) / res.meta["n_eff"]),
-               wall, res.meta["n_eff"], "samples/s")
-    if not only or "C3" in only:
-        n = int(1e9 * args.scale)
-        xs = np.linspace(0, 10, 512)
-        target = Distribution.from_pdf_table(xs, np.exp(-xs))
-        proposal = Distribution.normal(2.0, 3.0)
-        res, wall = timed(lambda: integ.integrate_importance_sampling([f1, f2, f3, f4], target, proposal, n_samples=n),
-                          args.repeat)
-        qpdf = lambda x: np.exp(-0.5 * ((x - 2.0) / 3.0) ** 2) / (3.0 * np.sqrt(2 * np.pi))
-        mu, var = table_moments(target._x_table.astype(np.float64), target._pdf_table.astype(np.float64), qpdf, 4)
-        report("C3 importance sampling K=4, 512-pt target table, N(2,3) proposal, n=1e9", res, mu,
-               np.sqrt(var / res.meta["n_eff"]), wall, res.meta["n_eff"], "samples/s")
-    if not only or "C4" in only:
-        chains = int(1_048_576 * args.scale)
-        target = Distribution.from_pdf(bimodal, support=(-10, 10))
-        proposal = Distribution.normal(0.0, 2.0)
-        res, wall = timed(lambda: integ.integrate_mcmc([f1, f2], target, proposal, n_steps=10_000, n_chains=chains,
-                                                       n_burnin=1000), max(1, args.repeat - 1))
-        steps = (res.meta["n_eff"] // 10_000) * 11_000
-        # independence sampler: integrated autocorrelation ~ (2 - a)/a with acceptance a ~ 0.66
-        tau = (2 - res.meta["accept_rate"]) / res.meta["accept_rate"]
-        # bimodal +-2 unit normals: E x^2 = 5, E x^4 = 3 + 6*4 + 16 = 43 -> var(x^2) = 18
-        sig = np.sqrt(np.array([5.0, 18.0]) * tau / res.meta["n_eff"])
-        report("C4 MCMC K=2 bimodal target, N(0,2) proposal, 1048576 chains x (1000 + 10000) steps", res, [0, 5], sig,
-               wall, steps, "MH steps/s")
+    for name in ("C1", "C2", "C3", "C4"):
+        if only and name not in only:
+            continue
+        wl = bc.get(name.lower(), Distribution)
+        size = max(int(wl.nominal * args.scale), 1)
+        res, wall = timed(lambda: wl.blocking(integ, size, 42), args.repeat if name != "C4" else max(1, args.repeat - 1))
+        truth, band = wl.band(res.meta["n_eff"], res.meta["accept_rate"]) if name == "C4" else wl.band(res.meta["n_eff"])
+        report(name + " " + wl.title, res, truth, band / 3.0, wall, wl.units(res.meta["n_eff"]), wl.unit, name.lower())
     if "C4RW" in only or "C4D" in only or "C4A" in only:
         # extensions either side of C4: random-walk proposals and the batch-means diagnostics, at C4's size
         chains = int(1_048_576 * args.scale)
@@ -151,22 +112,11 @@ def main():
                 print(json.dumps(dict(config=name, tau_int=out[-1]["tau_int"], ess=out[-1]["ess"],
                                       step_scale=out[-1].get("step_scale"))), flush=True)
     if not only or "C5" in only:
-        n = int(1e10 * args.scale)
-        fns = [lambda x, k=k: x**k for k in range(1, 33)]      # bound defaults -> constants -> shared multiply chain
-        dist = Distribution.beta(2.0, 5.0)
-        res, wall = timed(lambda: integ.integrate(fns, dist, n_samples=n), args.repeat)
-
-        def beta_moment(k):
-            m = 1.0
-            for j in range(k):
-                m *= (2 + j) / (7 + j)
-            return m
-
-        truth = np.array([beta_moment(k) for k in range(1, 33)])
-        var = np.array([beta_moment(2 * k) - beta_moment(k) ** 2 for k in range(1, 33)])
-        # the 2048-point CDF table has a discretisation bias of ~1e-4 relative: add it to the band
-        report("C5 integrate K=32 x^k, Beta(2,5) CDF table, n=1e10", res, truth,
-               np.sqrt(var / res.meta["n_eff"]) + truth * 2e-4 / 3, wall, res.meta["n_eff"], "samples/s")
+        wl = bc.get("c5", Distribution)
+        size = max(int(wl.nominal * args.scale), 1)
+        res, wall = timed(lambda: wl.blocking(integ, size, 42), args.repeat)
+        truth, band = wl.band(res.meta["n_eff"])
+        report("C5 " + wl.title, res, truth, band / 3.0, wall, wl.units(res.meta["n_eff"]), wl.unit, "c5")
     return 0
 
 

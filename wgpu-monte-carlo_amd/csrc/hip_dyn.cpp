@@ -33,16 +33,21 @@ static void* open_runtime(std::string* name) {
 template <class F>
 static bool bind(void* lib, const char* symbol, F* slot, std::string* why) {
     void* p = dlsym(lib, symbol);
-    if (!p) { *why = std::string("HIP runtime lacks ") + symbol; return false; }
+    if (!p) { *why = std::string("the library lacks the symbol ") + symbol; return false; }
     *slot = reinterpret_cast<F>(p);
     return true;
 }
 
 const HipApi* hip_api(const char** why) {
     std::call_once(g_once, [] {
+      try {
         static std::string name;
         void* lib = open_runtime(&name);
-        if (!lib) { g_why = std::string("no HIP runtime (libamdhip64) could be loaded: ") + (dlerror() ? dlerror() : ""); return; }
+        if (!lib) {                       // dlerror() clears the error it returns: read it exactly once
+            const char* err = dlerror();
+            g_why = std::string("no HIP runtime (libamdhip64) could be loaded: ") + (err ? err : "");
+            return;
+        }
         HipApi& a = g_api;
         std::string& w = g_why;
         g_ok = bind(lib, "hipGetErrorString", &a.GetErrorString, &w) && bind(lib, "hipGetDeviceCount", &a.GetDeviceCount, &w) &&
@@ -56,8 +61,11 @@ const HipApi* hip_api(const char** why) {
                bind(lib, "hipMemcpy", &a.Memcpy, &w) && bind(lib, "hipMemcpyAsync", &a.MemcpyAsync, &w) &&
                bind(lib, "hipMemsetAsync", &a.MemsetAsync, &w) && bind(lib, "hipModuleLoadData", &a.ModuleLoadData, &w) &&
                bind(lib, "hipModuleUnload", &a.ModuleUnload, &w) && bind(lib, "hipModuleGetFunction", &a.ModuleGetFunction, &w) &&
-               bind(lib, "hipModuleLaunchKernel", &a.ModuleLaunchKernel, &w);
+               bind(lib, "hipModuleLaunchKernel", &a.ModuleLaunchKernel, &w) &&
+               bind(lib, "hipFuncGetAttribute", &a.FuncGetAttribute, &w) && bind(lib, "hipStreamWaitEvent", &a.StreamWaitEvent, &w) &&
+               bind(lib, "hipEventCreateWithFlags", &a.EventCreateWithFlags, &w);
         a.library = name.c_str();
+      } catch (...) { g_ok = false; g_why = "exception while binding the HIP runtime"; }
     });
     if (!g_ok) {
         if (why) *why = g_why.c_str();
@@ -73,6 +81,7 @@ static std::once_flag g_rtc_once;
 
 const HiprtcApi* hiprtc_api(const char** why) {
     std::call_once(g_rtc_once, [] {
+      try {
         static std::string name;
         void* lib = nullptr;
         const char* env = getenv("MCX_HIPRTC");
@@ -81,7 +90,11 @@ const HiprtcApi* hiprtc_api(const char** why) {
             if (!*cand) continue;
             if ((lib = dlopen(cand, RTLD_NOW | RTLD_LOCAL))) { name = cand; break; }
         }
-        if (!lib) { g_rtc_why = std::string("hiprtc could not be loaded: ") + (dlerror() ? dlerror() : ""); return; }
+        if (!lib) {
+            const char* err = dlerror();
+            g_rtc_why = std::string("hiprtc could not be loaded: ") + (err ? err : "");
+            return;
+        }
         HiprtcApi& a = g_rtc;
         std::string& w = g_rtc_why;
         g_rtc_ok = bind(lib, "hiprtcCreateProgram", &a.CreateProgram, &w) && bind(lib, "hiprtcCompileProgram", &a.CompileProgram, &w) &&
@@ -90,12 +103,53 @@ const HiprtcApi* hiprtc_api(const char** why) {
                    bind(lib, "hiprtcDestroyProgram", &a.DestroyProgram, &w) && bind(lib, "hiprtcVersion", &a.Version, &w) &&
                    bind(lib, "hiprtcGetErrorString", &a.GetErrorString, &w);
         a.library = name.c_str();
+      } catch (...) { g_rtc_ok = false; g_rtc_why = "exception while binding hiprtc"; }
     });
     if (!g_rtc_ok) {
         if (why) *why = g_rtc_why.c_str();
         return nullptr;
     }
     return &g_rtc;
+}
+
+static RcclApi g_rccl;
+static bool g_rccl_ok = false;
+static std::string g_rccl_why;
+static std::once_flag g_rccl_once;
+
+const RcclApi* rccl_api(const char** why) {
+    std::call_once(g_rccl_once, [] {
+      try {
+        static std::string name;
+        void* lib = nullptr;
+        for (const char* cand : {"librccl.so", "librccl.so.1"})               // torch's bundled copy has no soname
+            if ((lib = dlopen(cand, RTLD_NOW | RTLD_NOLOAD))) { name = std::string(cand) + " (already loaded)"; break; }
+        if (!lib) {
+            const char* env = getenv("MCX_RCCL");
+            for (const char* cand : {env ? env : "", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+                if (!*cand) continue;
+                if ((lib = dlopen(cand, RTLD_NOW | RTLD_GLOBAL))) { name = cand; break; }
+            }
+        }
+        if (!lib) {
+            const char* err = dlerror();
+            g_rccl_why = std::string("RCCL (librccl) could not be loaded: ") + (err ? err : "");
+            return;
+        }
+        RcclApi& a = g_rccl;
+        std::string& w = g_rccl_why;
+        g_rccl_ok = bind(lib, "ncclCommInitAll", &a.CommInitAll, &w) && bind(lib, "ncclCommDestroy", &a.CommDestroy, &w) &&
+                    bind(lib, "ncclAllReduce", &a.AllReduce, &w) && bind(lib, "ncclGroupStart", &a.GroupStart, &w) &&
+                    bind(lib, "ncclGroupEnd", &a.GroupEnd, &w) && bind(lib, "ncclGetVersion", &a.GetVersion, &w) &&
+                    bind(lib, "ncclGetErrorString", &a.GetErrorString, &w);
+        a.library = name.c_str();
+      } catch (...) { g_rccl_ok = false; g_rccl_why = "exception while binding RCCL"; }
+    });
+    if (!g_rccl_ok) {
+        if (why) *why = g_rccl_why.c_str();
+        return nullptr;
+    }
+    return &g_rccl;
 }
 
 }  // namespace mcx

@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <hip/hiprtc.h>
+#include <rccl/rccl.h>
 
 namespace mcx {
 
@@ -37,6 +38,9 @@ struct HipApi {
     hipError_t (*ModuleGetFunction)(hipFunction_t*, hipModule_t, const char*);
     hipError_t (*ModuleLaunchKernel)(hipFunction_t, unsigned int, unsigned int, unsigned int, unsigned int,
                                      unsigned int, unsigned int, unsigned int, hipStream_t, void**, void**);
+    hipError_t (*FuncGetAttribute)(int*, hipFunction_attribute, hipFunction_t);
+    hipError_t (*StreamWaitEvent)(hipStream_t, hipEvent_t, unsigned int);
+    hipError_t (*EventCreateWithFlags)(hipEvent_t*, unsigned int);
     const char* library;      // path or soname of the runtime that was bound
 };
 
@@ -59,5 +63,20 @@ struct HiprtcApi {
     const char* library;
 };
 const HiprtcApi* hiprtc_api(const char** why = nullptr);
+
+// RCCL, bound the same way as the HIP runtime and for the same reason: PyTorch-ROCm bundles its own librccl.so
+// linked against its own libamdhip64.so. Preference: an instance already mapped in the process, MCX_RCCL, the
+// system library. Only the single-process entry points are used (one host thread drives every GPU of the node).
+struct RcclApi {
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*GroupStart)();
+    ncclResult_t (*GroupEnd)();
+    ncclResult_t (*GetVersion)(int*);
+    const char* (*GetErrorString)(ncclResult_t);
+    const char* library;
+};
+const RcclApi* rccl_api(const char** why = nullptr);
 
 }  // namespace mcx

@@ -25,10 +25,6 @@ from .frontend import TranspilerError
 
 FunctionLike = Union[Callable, str]
 
-# LDS budget for staged tables (csrc/mcx_runtime.cpp lds_dynamic_max(): 160 KiB per CU minus static scratch)
-_LDS_TABLE_BUDGET = 156 * 1024
-
-
 class IntegrationResult:
     """Expected values, one per function, in the order the functions were given."""
 
@@ -196,6 +192,19 @@ def _unit_params(code: int, p1: float, p2: float) -> bool:
     return code == runtime.DIST_EXPONENTIAL and p1 == 1.0
 
 
+class _Plan:
+    """One compiled call: the module, its resident tables and the scalar parameters -- everything except the sizes and
+    the seed, which are launch-time arguments. integrate* build a plan and launch it once; prepare_* hand it out."""
+
+    __slots__ = ("kind", "module", "desc", "k", "rows", "p1", "p2", "tables", "x0", "target_accept", "proposal_kind", "walk")
+
+    def __init__(self, kind, module, desc, k, rows, p1, p2, tables, x0=0.0, target_accept=0.44, proposal_kind="independent",
+                 walk=0):
+        self.kind, self.module, self.desc, self.k, self.rows = kind, module, desc, k, rows
+        self.p1, self.p2, self.tables = p1, p2, tables
+        self.x0, self.target_accept, self.proposal_kind, self.walk = x0, target_accept, proposal_kind, walk
+
+
 class MonteCarloIntegrator:
     """Fused multi-function Monte-Carlo integrator on one MI355X (or one rank of N).
 
@@ -203,8 +212,10 @@ class MonteCarloIntegrator:
         target_threads: logical thread count T of the reference's sample grid (default 65536). It
             fixes the sample indexing (T, L = ceil(n/T)), not the physical launch geometry.
         device: HIP device index (default: LOCAL_RANK if set, else 0).
-        process_group: torch.distributed group to shard over; default = the world group when
-            torch.distributed is initialised, else single GPU.
+        process_group: ranks to shard every call over. None (default): this GPU only, like the reference (set
+            MCX_DISTRIBUTED=1 to make None mean "world"); "world": the world group of the initialised
+            torch.distributed job; or a torch.distributed process group. Sharding is opt-in because every sharded
+            call is a collective: all ranks of the group must make it.
         math: "default" (hardware exp/log/sqrt/rcp within WGSL's accuracy contract, ocml sin/cos/pow),
             "fast" (also hardware sin/cos/tan) or "precise" (ocml + IEEE division everywhere).
         strict_reference_uniform: reproduce u = float(hash)*2^-32 on the closed interval [0,1]
@@ -238,7 +249,7 @@ class MonteCarloIntegrator:
         self._math = math
         self._precise_sampler = math == "precise"
         self._guard = not strict_reference_uniform
-        self._group = distributed.Group(process_group) if process_group is not None else distributed.default_group()
+        self._group = distributed.resolve_group(process_group)
 
     # ---- helpers ---------------------------------------------------------------------------------
     def _table(self, kind: int, keys: np.ndarray, values: np.ndarray) -> runtime.Table:
@@ -252,8 +263,15 @@ class MonteCarloIntegrator:
         return self._table(runtime.TABLE_CDF, dist._cdf_table, dist._x_table)
 
     @staticmethod
-    def _lds_bytes(*tables: Optional[runtime.Table]) -> int:
-        return sum(tb.lds_bytes for tb in tables if tb is not None)
+    def _fit_tables(desc, *tables: Optional[runtime.Table]):
+        """Decide desc.tables_lds: do the staged forms of these tables fit next to the module's static LDS (its
+        reduction scratch)? Same budget libmcx checks at launch (mcx_lds_table_budget). When they do not fit, the
+        module is built with tables_lds = 0 and the same code reads the tables from HBM / L2."""
+        need = sum(tb.lds_bytes for tb in tables if tb is not None)
+        desc.tables_lds = 1
+        if need > runtime.lds_table_budget(desc):
+            desc.tables_lds = 0
+        return desc
 
     def _run(self, rows: int, call):
         """Run one sharded launch and combine the ranks with ONE sum all-reduce of `rows` doubles.
@@ -305,43 +323,28 @@ class MonteCarloIntegrator:
     def _rank_world(self):
         return (self._group.rank, self._group.world) if self._group is not None else (0, 1)
 
-    # ---- K1 ----------------------------------------------------------------------------------------
-    def integrate(self, functions: List[FunctionLike], distribution: Distribution, n_samples: int = 1_000_000,
-                  seed: int = 42) -> IntegrationResult:
-        """E[f_k(X)], X ~ distribution, for all functions on the same samples."""
+    # ---- plans: emission + compilation + resident tables, no launch -----------------------------------
+    def _plan_integrate(self, functions, distribution) -> _Plan:
         if len(functions) == 0:
             raise ValueError("At least one function is required")
         user_src = functions_to_hip(functions, self._math)
-        n_samples = _check_count(n_samples, "n_samples")
-        seed = _check_seed(seed)
         code, p1, p2 = _dist_params(distribution)
         cdf = self._cdf_table(distribution)
-        lds_ok = self._lds_bytes(cdf) <= _LDS_TABLE_BUDGET
         k = len(functions)
         desc = runtime.make_desc(runtime.KIND_INTEGRATE, k, code, guard_endpoints=self._guard,
-                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng,
+                                 precise_sampler=self._precise_sampler, rng=self._rng,
                                  second_moments=self._std_error, unit_params=_unit_params(code, p1, p2),
                                  moment_family=self._use_moment_family(functions))
-        mod = self._engine.module(user_src, desc)
-        rank, world = self._rank_world()
-        values, n_eff = self._run(k * (2 if self._std_error else 1), lambda d_sums, stream: self._engine.integrate(
-            mod, n_samples, seed, p1, p2, self._target_threads, cdf=cdf, rank=rank, world=world,
-            d_sums=d_sums, stream=stream))
-        self._warn_if_oversubscribed(n_eff)
-        return IntegrationResult(values[:k], n_samples, k, self._meta(n_eff, values, k))
+        self._fit_tables(desc, cdf)
+        return _Plan("integrate", self._engine.module(user_src, desc), desc, k, runtime.result_rows(desc), p1, p2,
+                     dict(cdf=cdf))
 
-    # ---- K2 ----------------------------------------------------------------------------------------
-    def integrate_importance_sampling(self, functions: List[FunctionLike], target_distribution: Distribution,
-                                      proposal_distribution: Distribution, n_samples: int = 1_000_000,
-                                      seed: int = 42) -> IntegrationResult:
-        """E_p[f_k(X)] ~= mean f_k(x) p(x)/q(x), x ~ q."""
+    def _plan_importance_sampling(self, functions, target_distribution, proposal_distribution) -> _Plan:
         if len(functions) == 0:
             raise ValueError("At least one function is required")
         p_src = _pdf_to_hip(target_distribution, "mcx_pdf_p", self._math)
         q_src = _pdf_to_hip(proposal_distribution, "mcx_pdf_q", self._math)
         user_src = functions_to_hip(functions, self._math)
-        n_samples = _check_count(n_samples, "n_samples")
-        seed = _check_seed(seed)
         code, p1, p2 = _dist_params(proposal_distribution)
         cdf = self._cdf_table(proposal_distribution)
         p_table = q_table = None
@@ -359,21 +362,93 @@ class MonteCarloIntegrator:
             q_table = self._table(runtime.TABLE_PDF, xs, dens)
         elif not q_sampler:
             user_src += "\n\n" + q_src
-        lds_ok = self._lds_bytes(cdf, p_table, q_table) <= _LDS_TABLE_BUDGET
         k = len(functions)
         desc = runtime.make_desc(runtime.KIND_INTEGRATE, k, code, weight=True,
                                  p_table=p_table is not None, q_table=q_table is not None,
                                  guard_endpoints=self._guard, precise_sampler=self._precise_sampler,
-                                 tables_lds=lds_ok, rng=self._rng, second_moments=self._std_error,
+                                 rng=self._rng, second_moments=self._std_error,
                                  unit_params=_unit_params(code, p1, p2),
                                  cell_tables=self._cell_tables(p_table, q_table), q_sampler=q_sampler,
                                  moment_family=self._use_moment_family(functions))
-        mod = self._engine.module(user_src, desc)
-        rank, world = self._rank_world()
-        values, n_eff = self._run(k * (2 if self._std_error else 1), lambda d_sums, stream: self._engine.integrate(
-            mod, n_samples, seed, p1, p2, self._target_threads, cdf=cdf, target_pdf=p_table,
-            proposal_pdf=q_table, rank=rank, world=world, d_sums=d_sums, stream=stream))
-        return IntegrationResult(values[:k], n_samples, k, self._meta(n_eff, values, k))
+        self._fit_tables(desc, cdf, p_table, q_table)
+        return _Plan("integrate", self._engine.module(user_src, desc), desc, k, runtime.result_rows(desc), p1, p2,
+                     dict(cdf=cdf, target_pdf=p_table, proposal_pdf=q_table))
+
+    def _plan_mcmc(self, functions, target_distribution, proposal_distribution, proposal_kind="independent",
+                   initial_state=0.0, target_accept=0.44) -> _Plan:
+        if proposal_kind not in ("independent", "random_walk", "adaptive_random_walk"):
+            raise ValueError(f"Unknown proposal_kind: {proposal_kind!r} (expected 'independent', 'random_walk' or "
+                             f"'adaptive_random_walk')")
+        if proposal_kind == "adaptive_random_walk" and not 0.0 < float(target_accept) < 1.0:
+            raise ValueError("target_accept must lie strictly between 0 and 1")
+        if len(functions) == 0:
+            raise ValueError("At least one function is required")
+        user_src = functions_to_hip(functions, self._math)
+        code, p1, p2 = _dist_params(proposal_distribution)
+        # Distribution.normal proposals: log q(x) = -z^2/2 + const for the deviate z the sampler holds, so no proposal
+        # table is interpolated (the reference's 2048-point table of the same function is up to 6e-6 below it)
+        q_sampler = (code == runtime.DIST_NORMAL and not self._precise_sampler
+                     and _is_factory_normal(proposal_distribution, p1, p2))
+        tx, tlog = target_distribution.get_log_pdf_table()
+        t_table = self._table(runtime.TABLE_LOGPDF, tx, tlog)
+        q_table = None
+        if not q_sampler:
+            px, plog = proposal_distribution.get_log_pdf_table()
+            q_table = self._table(runtime.TABLE_LOGPDF, px, plog)
+        cdf = self._cdf_table(proposal_distribution)
+        walk = runtime.WALK_INDEPENDENT
+        if proposal_kind != "independent":
+            symmetric = (code == runtime.DIST_NORMAL and p1 == 0.0) or (code == runtime.DIST_UNIFORM and p1 == -p2)
+            walk = runtime.WALK_RANDOM_SYMMETRIC if symmetric else runtime.WALK_RANDOM
+            if proposal_kind == "adaptive_random_walk":
+                if not symmetric:
+                    raise ValueError("adaptive_random_walk needs increments symmetric about 0: normal(0, s) or uniform(-w, w)")
+                walk = runtime.WALK_ADAPTIVE
+        k = len(functions)
+        desc = runtime.make_desc(runtime.KIND_MCMC, k, code, guard_endpoints=self._guard,
+                                 precise_sampler=self._precise_sampler, rng=self._rng,
+                                 unit_params=_unit_params(code, p1, p2), second_moments=self._std_error, walk=walk,
+                                 cell_tables=self._cell_tables(t_table, q_table), q_sampler=q_sampler)
+        self._fit_tables(desc, cdf, t_table, q_table)
+        return _Plan("mcmc", self._engine.module(user_src, desc), desc, k, runtime.result_rows(desc), p1, p2,
+                     dict(cdf=cdf, target_logpdf=t_table, proposal_logpdf=q_table), x0=float(initial_state),
+                     target_accept=float(target_accept), proposal_kind=proposal_kind, walk=walk)
+
+    def _enqueue(self, plan: _Plan, sizes, seed: int, d_sums, stream, rank_world=None):
+        """Launch this rank's shard of `plan`: (host sums or None when d_sums is given, n_eff of the WHOLE job)."""
+        rank, world = rank_world if rank_world is not None else self._rank_world()
+        tb = plan.tables
+        if plan.kind == "mcmc":
+            n_steps, n_chains, n_burnin = sizes
+            return self._engine.mcmc(plan.module, n_steps, n_chains, n_burnin, seed, plan.p1, plan.p2,
+                                     tb["target_logpdf"], tb["proposal_logpdf"], target_threads=self._target_threads,
+                                     cdf=tb["cdf"], rank=rank, world=world, d_sums=d_sums, stream=stream,
+                                     x0=plan.x0, target_accept=plan.target_accept)
+        return self._engine.integrate(plan.module, sizes, seed, plan.p1, plan.p2, self._target_threads, cdf=tb.get("cdf"),
+                                      target_pdf=tb.get("target_pdf"), proposal_pdf=tb.get("proposal_pdf"),
+                                      rank=rank, world=world, d_sums=d_sums, stream=stream)
+
+    # ---- K1 ----------------------------------------------------------------------------------------
+    def integrate(self, functions: List[FunctionLike], distribution: Distribution, n_samples: int = 1_000_000,
+                  seed: int = 42) -> IntegrationResult:
+        """E[f_k(X)], X ~ distribution, for all functions on the same samples."""
+        plan = self._plan_integrate(functions, distribution)
+        n_samples = _check_count(n_samples, "n_samples")
+        seed = _check_seed(seed)
+        values, n_eff = self._run(plan.rows, lambda d_sums, stream: self._enqueue(plan, n_samples, seed, d_sums, stream))
+        self._warn_if_oversubscribed(n_eff)
+        return IntegrationResult(values[:plan.k], n_samples, plan.k, self._meta(n_eff, values, plan.k))
+
+    # ---- K2 ----------------------------------------------------------------------------------------
+    def integrate_importance_sampling(self, functions: List[FunctionLike], target_distribution: Distribution,
+                                      proposal_distribution: Distribution, n_samples: int = 1_000_000,
+                                      seed: int = 42) -> IntegrationResult:
+        """E_p[f_k(X)] ~= mean f_k(x) p(x)/q(x), x ~ q."""
+        plan = self._plan_importance_sampling(functions, target_distribution, proposal_distribution)
+        n_samples = _check_count(n_samples, "n_samples")
+        seed = _check_seed(seed)
+        values, n_eff = self._run(plan.rows, lambda d_sums, stream: self._enqueue(plan, n_samples, seed, d_sums, stream))
+        return IntegrationResult(values[:plan.k], n_samples, plan.k, self._meta(n_eff, values, plan.k))
 
     # ---- K3 ----------------------------------------------------------------------------------------
     def integrate_mcmc(self, functions: List[FunctionLike], target_distribution: Distribution,
@@ -398,50 +473,28 @@ class MonteCarloIntegrator:
             raise ValueError("target_accept must lie strictly between 0 and 1")
         if len(functions) == 0:
             raise ValueError("At least one function is required")
+        n_steps, n_chains, n_burnin = self._check_mcmc_sizes(n_steps, n_chains, n_burnin)
+        seed = _check_seed(seed)
+        plan = self._plan_mcmc(functions, target_distribution, proposal_distribution, proposal_kind, initial_state,
+                               target_accept)
+        values, n_eff = self._run(plan.rows, lambda d_sums, stream: self._enqueue(
+            plan, (n_steps, n_chains, n_burnin), seed, d_sums, stream))
+        return self._mcmc_result(plan, values, n_eff, n_steps, n_chains, n_burnin)
+
+    @staticmethod
+    def _check_mcmc_sizes(n_steps, n_chains, n_burnin):
         if n_steps <= 0:
             raise ValueError("n_steps must be positive")
         if n_chains <= 0:
             raise ValueError("n_chains must be positive")
         if n_burnin < 0:
             raise ValueError("n_burnin must be non-negative")
-        user_src = functions_to_hip(functions, self._math)
-        n_steps = _check_count(n_steps, "n_steps", 32)
-        n_chains = _check_count(n_chains, "n_chains", 32)
-        n_burnin = _check_count(n_burnin, "n_burnin", 32)
-        seed = _check_seed(seed)
-        code, p1, p2 = _dist_params(proposal_distribution)
-        # Distribution.normal proposals: log q(x) = -z^2/2 + const for the deviate z the sampler holds, so no proposal
-        # table is interpolated (the reference's 2048-point table of the same function is up to 6e-6 below it)
-        q_sampler = (code == runtime.DIST_NORMAL and not self._precise_sampler
-                     and _is_factory_normal(proposal_distribution, p1, p2))
-        tx, tlog = target_distribution.get_log_pdf_table()
-        t_table = self._table(runtime.TABLE_LOGPDF, tx, tlog)
-        q_table = None
-        if not q_sampler:
-            px, plog = proposal_distribution.get_log_pdf_table()
-            q_table = self._table(runtime.TABLE_LOGPDF, px, plog)
-        cdf = self._cdf_table(proposal_distribution)
-        lds_ok = self._lds_bytes(cdf, t_table, q_table) <= _LDS_TABLE_BUDGET
-        walk = runtime.WALK_INDEPENDENT
-        if proposal_kind != "independent":
-            symmetric = (code == runtime.DIST_NORMAL and p1 == 0.0) or (code == runtime.DIST_UNIFORM and p1 == -p2)
-            walk = runtime.WALK_RANDOM_SYMMETRIC if symmetric else runtime.WALK_RANDOM
-            if proposal_kind == "adaptive_random_walk":
-                if not symmetric:
-                    raise ValueError("adaptive_random_walk needs increments symmetric about 0: normal(0, s) or uniform(-w, w)")
-                walk = runtime.WALK_ADAPTIVE
-        desc = runtime.make_desc(runtime.KIND_MCMC, len(functions), code, guard_endpoints=self._guard,
-                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng,
-                                 unit_params=_unit_params(code, p1, p2), second_moments=self._std_error, walk=walk,
-                                 cell_tables=self._cell_tables(t_table, q_table), q_sampler=q_sampler)
-        mod = self._engine.module(user_src, desc)
-        rank, world = self._rank_world()
-        k = len(functions)
-        rows = runtime.result_rows(desc)
-        values, n_eff = self._run(rows, lambda d_sums, stream: self._engine.mcmc(
-            mod, n_steps, n_chains, n_burnin, seed, p1, p2, t_table, q_table,
-            target_threads=self._target_threads, cdf=cdf, rank=rank, world=world, d_sums=d_sums, stream=stream,
-            x0=float(initial_state), target_accept=float(target_accept)))
+        return (_check_count(n_steps, "n_steps", 32), _check_count(n_chains, "n_chains", 32),
+                _check_count(n_burnin, "n_burnin", 32))
+
+    def _mcmc_result(self, plan: _Plan, values, n_eff: int, n_steps: int, n_chains: int, n_burnin: int) -> IntegrationResult:
+        """values = all-rank sums / n_eff for every result row of an MCMC plan -> the public result + diagnostics."""
+        k = plan.k
         meta = self._meta(n_eff)
         total_chains = n_eff // n_steps
         # chains whose counters collide replay each other's random numbers with a time shift: the estimate stays
@@ -450,8 +503,8 @@ class MonteCarloIntegrator:
         self._warn_if_oversubscribed(2 * total_chains * (n_steps + n_burnin), "uniform draws (chains x steps x 2)")
         row_accept = 2 * k if self._std_error else k
         meta["accept_rate"] = float(values[row_accept]) * n_eff / (float(total_chains) * (n_steps + n_burnin))
-        meta["proposal_kind"] = proposal_kind
-        if walk == runtime.WALK_ADAPTIVE:
+        meta["proposal_kind"] = plan.proposal_kind
+        if plan.walk == runtime.WALK_ADAPTIVE:
             meta["step_scale"] = float(values[-1]) * n_eff / float(total_chains)      # mean final scale over the chains
         if self._std_error:
             # batch means with one batch per chain: chains are independent, so the spread of their means measures
@@ -465,22 +518,25 @@ class MonteCarloIntegrator:
                 meta["ess"] = float(n_eff) / meta["tau_int"]
         return IntegrationResult(values[:k], n_chains * n_steps, k, meta)
 
-    # ---- prepared (asynchronous) form of K1 ---------------------------------------------------------
+    # ---- prepared (asynchronous) forms ---------------------------------------------------------------
     def prepare_integrate(self, functions: List[FunctionLike], distribution: Distribution) -> "PreparedIntegrand":
         """Emit + compile once; the returned object launches without host synchronisation.
 
         Extension over the reference API for serving / benchmarking loops: every `integrate()` call of the
         reference re-transpiles and re-compiles (src/engine.rs:325-331)."""
-        if len(functions) == 0:
-            raise ValueError("At least one function is required")
-        user_src = functions_to_hip(functions, self._math)
-        code, p1, p2 = _dist_params(distribution)
-        cdf = self._cdf_table(distribution)
-        lds_ok = self._lds_bytes(cdf) <= _LDS_TABLE_BUDGET
-        desc = runtime.make_desc(runtime.KIND_INTEGRATE, len(functions), code, guard_endpoints=self._guard,
-                                 precise_sampler=self._precise_sampler, tables_lds=lds_ok, rng=self._rng,
-                                 unit_params=_unit_params(code, p1, p2))
-        return PreparedIntegrand(self, self._engine.module(user_src, desc), len(functions), p1, p2, cdf)
+        return PreparedIntegrand(self, self._plan_integrate(functions, distribution))
+
+    def prepare_importance_sampling(self, functions: List[FunctionLike], target_distribution: Distribution,
+                                    proposal_distribution: Distribution) -> "PreparedIntegrand":
+        """prepare_integrate for integrate_importance_sampling (same launch interface)."""
+        return PreparedIntegrand(self, self._plan_importance_sampling(functions, target_distribution, proposal_distribution))
+
+    def prepare_mcmc(self, functions: List[FunctionLike], target_distribution: Distribution,
+                     proposal_distribution: Distribution, proposal_kind: str = "independent", initial_state: float = 0.0,
+                     target_accept: float = 0.44) -> "PreparedMcmc":
+        """prepare_integrate for integrate_mcmc: launch(n_steps, n_chains, n_burnin, seed, out)."""
+        return PreparedMcmc(self, self._plan_mcmc(functions, target_distribution, proposal_distribution, proposal_kind,
+                                                  initial_state, target_accept))
 
     def _meta(self, n_eff: int, values=None, k: int = 0) -> dict:
         launch = self._engine.last_launch()
@@ -495,41 +551,59 @@ class MonteCarloIntegrator:
 
 
 class PreparedIntegrand:
-    """A compiled fused integrand bound to one engine (see MonteCarloIntegrator.prepare_integrate)."""
+    """A compiled fused integrand (integrate / importance sampling) bound to one engine: see
+    MonteCarloIntegrator.prepare_integrate / prepare_importance_sampling."""
 
-    def __init__(self, owner: MonteCarloIntegrator, module: runtime.Module, k: int, p1: float, p2: float,
-                 cdf: Optional[runtime.Table]):
-        self._owner, self._module, self.k = owner, module, k
-        self._p1, self._p2, self._cdf = p1, p2, cdf
+    def __init__(self, owner: MonteCarloIntegrator, plan: _Plan):
+        self._owner, self._plan = owner, plan
+        self.k, self.rows = plan.k, plan.rows
 
-    def launch(self, n_samples: int, seed: int, out, async_op: bool = False):
-        """Enqueue sampling + reduction (+ one sum all-reduce when sharded) on torch's current stream.
-
-        `out` is a float64 CUDA tensor with k elements that receives the SUMS over the whole job (all
-        ranks); divide by the returned n_eff for the expected values. No host synchronisation.
-        With async_op=True the collective does not block the current stream (the next launch overlaps it);
-        returns (n_eff, work) and the caller waits on `work` (None on a single GPU) before reading `out`."""
+    def _launch(self, sizes, seed: int, out, async_op: bool, reduce: bool):
         import torch
 
         owner = self._owner
-        rank, world = owner._rank_world()
+        if out.dtype != torch.float64 or out.numel() < self.rows or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous float64 CUDA tensor with at least {self.rows} elements")
         stream = torch.cuda.current_stream(out.device).cuda_stream
-        _, n_eff = owner._engine.integrate(self._module, n_samples, seed, self._p1, self._p2,
-                                           owner._target_threads, cdf=self._cdf, rank=rank, world=world,
-                                           d_sums=out.data_ptr(), stream=stream)
+        _, n_eff = owner._enqueue(self._plan, sizes, seed, out.data_ptr(), stream)
         work = None
-        if world > 1:
+        if reduce and owner._rank_world()[1] > 1:
             work = distributed.all_reduce_device(owner._group, out, async_op=async_op)
         return (n_eff, work) if async_op else n_eff
 
+    def launch(self, n_samples: int, seed: int, out, async_op: bool = False, reduce: bool = True):
+        """Enqueue sampling + reduction (+ one sum all-reduce when sharded) on torch's current stream.
+
+        `out` is a float64 CUDA tensor with `rows` (= k; 2k with std_error) elements that receives the SUMS over the
+        whole job (all ranks); divide by the returned n_eff for the expected values. No host synchronisation.
+        With async_op=True the collective does not block the current stream (the next launch overlaps it);
+        returns (n_eff, work) and the caller waits on `work` (None on a single GPU) before reading `out`.
+        reduce=False leaves this rank's partial sums in `out` (no collective)."""
+        return self._launch(int(n_samples), seed, out, async_op, reduce)
+
     def run(self, n_samples: int, seed: int = 42) -> IntegrationResult:
-        """Blocking form: same result as MonteCarloIntegrator.integrate()."""
-        owner = self._owner
-        rank, world = owner._rank_world()
-        values, n_eff = owner._run(self.k, lambda d_sums, stream: owner._engine.integrate(
-            self._module, n_samples, seed, self._p1, self._p2, owner._target_threads, cdf=self._cdf,
-            rank=rank, world=world, d_sums=d_sums, stream=stream))
-        return IntegrationResult(values, n_samples, self.k, owner._meta(n_eff))
+        """Blocking form: same result as MonteCarloIntegrator.integrate() / integrate_importance_sampling()."""
+        owner, plan = self._owner, self._plan
+        values, n_eff = owner._run(plan.rows, lambda d_sums, stream: owner._enqueue(plan, int(n_samples), seed, d_sums, stream))
+        return IntegrationResult(values[:plan.k], n_samples, plan.k, owner._meta(n_eff, values, plan.k))
+
+
+class PreparedMcmc(PreparedIntegrand):
+    """A compiled Metropolis-Hastings call (MonteCarloIntegrator.prepare_mcmc). `rows` = k + 1 (row k: accepted steps;
+    3k + 1 with std_error, one more for the adaptive walk)."""
+
+    def launch(self, n_steps: int, n_chains: int, n_burnin: int, seed: int, out, async_op: bool = False,
+               reduce: bool = True):
+        """Enqueue this rank's chains (+ one sum all-reduce when sharded); `out` receives `rows` sums, n_eff =
+        padded chains x n_steps is returned. See PreparedIntegrand.launch."""
+        return self._launch(MonteCarloIntegrator._check_mcmc_sizes(n_steps, n_chains, n_burnin), seed, out, async_op, reduce)
+
+    def run(self, n_steps: int = 10_000, n_chains: int = 1024, n_burnin: int = 1_000, seed: int = 42) -> IntegrationResult:
+        """Blocking form: same result as MonteCarloIntegrator.integrate_mcmc()."""
+        owner, plan = self._owner, self._plan
+        sizes = MonteCarloIntegrator._check_mcmc_sizes(n_steps, n_chains, n_burnin)
+        values, n_eff = owner._run(plan.rows, lambda d_sums, stream: owner._enqueue(plan, sizes, seed, d_sums, stream))
+        return owner._mcmc_result(plan, values, n_eff, *sizes)
 
 
 def integrate(functions: List[FunctionLike], distribution: Distribution, n_samples: int = 1_000_000, seed: int = 42,

@@ -28,16 +28,38 @@ class Group:
         self.backend = dist.get_backend(process_group)
 
 
-def default_group() -> Optional[Group]:
-    """The world group if the caller initialised torch.distributed with more than one rank, else None.
+def world_group() -> Optional[Group]:
+    """The world group of an initialised torch.distributed job with more than one rank, else None.
     Never imports torch by itself: a process that has not imported torch cannot have a process group."""
     torch = sys.modules.get("torch")
-    if torch is None or os.environ.get("MCX_DISTRIBUTED", "1") == "0":
+    if torch is None:
         return None
     dist = getattr(torch, "distributed", None)
     if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() < 2:
         return None
     return Group()
+
+
+def default_group() -> Optional[Group]:
+    """What an integrator built without `process_group` shards over: nothing, unless MCX_DISTRIBUTED=1 is set.
+
+    Sharding is opt-in (MonteCarloIntegrator(process_group="world" | <torch group>)): every sharded call is a
+    collective, so an integrate() issued by one rank only of a data-parallel training job -- a drop-in user of the
+    reference's single-device API -- would otherwise hang in the all-reduce."""
+    if os.environ.get("MCX_DISTRIBUTED", "0") != "1":
+        return None
+    return world_group()
+
+
+def resolve_group(process_group) -> Optional[Group]:
+    """None -> default_group(); "world" -> the world group (None when the job has a single rank); else a torch group."""
+    if process_group is None:
+        return default_group()
+    if isinstance(process_group, str):
+        if process_group != "world":
+            raise ValueError("process_group must be None, 'world' or a torch.distributed process group")
+        return world_group()
+    return Group(process_group)
 
 
 def all_reduce_host(group: Optional[Group], sums: np.ndarray) -> np.ndarray:

@@ -72,6 +72,9 @@ EXPORTED_SYMBOLS = [
     "mcx_module_precompile", "mcx_result_rows", "mcx_module_source", "mcx_free", "mcx_module_release", "mcx_cache_dir",
     "mcx_table_create", "mcx_table_release", "mcx_table_info", "mcx_table_lds_bytes", "mcx_table_cell_map", "mcx_table_has_cells", "mcx_table_cells", "mcx_integrate", "mcx_integrate_device",
     "mcx_mcmc", "mcx_mcmc_device", "mcx_integrate_multi", "mcx_mcmc_multi",
+    "mcx_engine_last_launch_count", "mcx_module_static_lds", "mcx_lds_table_budget", "mcx_rccl_library",
+    "mcx_comm_create", "mcx_comm_destroy", "mcx_comm_size", "mcx_integrate_comm", "mcx_mcmc_comm",
+    "mcx_selftest_streams", "mcx_set_max_launch_units",
 ]
 
 _lib = None
@@ -93,13 +96,19 @@ def _share_torch_hip_runtime() -> None:
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return
-    cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+    lib_dir = Path(list(spec.submodule_search_locations)[0]) / "lib"
+    cand = lib_dir / "libamdhip64.so"
     if cand.exists():
         try:
             C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
             os.environ["MCX_HIP_RUNTIME"] = str(cand)
         except OSError:
-            pass
+            return
+        # the same goes for RCCL (mcx_comm_*): torch's librccl.so is linked against torch's HIP runtime, the system
+        # one against the system runtime -- bind the one that matches the runtime just mapped
+        rccl = lib_dir / "librccl.so"
+        if rccl.exists() and not os.environ.get("MCX_RCCL"):
+            os.environ["MCX_RCCL"] = str(rccl)
 
 
 def load():
@@ -161,6 +170,24 @@ def load():
                                           C.POINTER(C.c_double), C.POINTER(u64)]
         L.mcx_mcmc_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(C.POINTER(McmcParams)), C.c_int,
                                      C.POINTER(C.c_double), C.POINTER(u64)]
+        L.mcx_engine_last_launch_count.argtypes = [vp]
+        L.mcx_engine_last_launch_count.restype = u32
+        L.mcx_module_static_lds.argtypes = [vp]
+        L.mcx_module_static_lds.restype = u32
+        L.mcx_lds_table_budget.argtypes = [C.POINTER(ModuleDesc)]
+        L.mcx_lds_table_budget.restype = u32
+        L.mcx_rccl_library.restype = C.c_char_p
+        L.mcx_comm_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
+        L.mcx_comm_destroy.argtypes = [vp]
+        L.mcx_comm_destroy.restype = None
+        L.mcx_comm_size.argtypes = [vp]
+        L.mcx_integrate_comm.argtypes = [vp, C.POINTER(vp), C.POINTER(C.POINTER(IntegrateParams)), C.POINTER(C.c_double),
+                                         C.POINTER(u64)]
+        L.mcx_mcmc_comm.argtypes = [vp, C.POINTER(vp), C.POINTER(C.POINTER(McmcParams)), C.POINTER(C.c_double), C.POINTER(u64)]
+        u32p = C.POINTER(u32)
+        L.mcx_selftest_streams.argtypes = [vp, u32, u32p, u32p, u32p, u32p, u32p, C.POINTER(C.c_float), u32, u32p, u32p, u32p]
+        L.mcx_set_max_launch_units.argtypes = [u64]
+        L.mcx_set_max_launch_units.restype = None
         _lib = L
         return _lib
 
@@ -251,6 +278,16 @@ def result_rows(desc: ModuleDesc) -> int:
     return rows
 
 
+def set_max_launch_units(units: int) -> None:
+    """Work bound of one main-kernel launch (0 = default); larger calls are split (include/mcx.h)."""
+    load().mcx_set_max_launch_units(int(units))
+
+
+def lds_table_budget(desc: ModuleDesc) -> int:
+    """LDS bytes a module built from `desc` leaves for staged tables (include/mcx.h: mcx_lds_table_budget)."""
+    return int(load().mcx_lds_table_budget(C.byref(desc)))
+
+
 def module_source(user_src: str, desc: ModuleDesc) -> str:
     out = C.c_void_p()
     check(load().mcx_module_source(user_src.encode(), C.byref(desc), C.byref(out)))
@@ -324,10 +361,11 @@ class Module:
         self.desc = desc
         self._h = C.c_void_p()
         check(load().mcx_module_build(engine._h, user_src.encode(), C.byref(desc), C.byref(self._h)))
+        self.static_lds = int(load().mcx_module_static_lds(self._h))
 
     def release(self) -> None:
         if self._h:
-            load().mcx_module_release(self._h)
+            load().mcx_module_release(self._h)      # waits for the module's last launch before unloading the code
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -379,24 +417,53 @@ class Engine:
         key = (kind, keys.tobytes(), values.tobytes())
         tb = self._tables.get(key)
         if tb is None:
-            if len(self._tables) > 64:
-                self._tables.clear()
+            while len(self._tables) >= 64:
+                self._tables.pop(next(iter(self._tables)))            # oldest first; in-use tables stay referenced by plans
             tb = Table(self, kind, keys, values)
-            self._tables[key] = tb
+        else:
+            del self._tables[key]
+        self._tables[key] = tb
         return tb
 
+    MAX_MODULES = 256
+
     def module(self, user_src: str, desc: ModuleDesc) -> Module:
+        """Loaded module for (source, desc): least recently used out beyond MAX_MODULES. An evicted module is released
+        when its last user drops it (plans / prepared integrands hold references), and mcx_module_release waits for
+        the module's last launch before it unloads the code object."""
         key = (user_src, bytes(desc))
-        mod = self._modules.get(key)
+        mod = self._modules.pop(key, None)
         if mod is None:
             mod = Module(self, user_src, desc)
-            if len(self._modules) > 256:
-                self._modules.clear()
-            self._modules[key] = mod
+            while len(self._modules) >= self.MAX_MODULES:
+                self._modules.pop(next(iter(self._modules)))         # dicts keep insertion order: the oldest entry
+        self._modules[key] = mod                                      # (re-)insert as the most recent
         return mod
 
     def table(self, kind: int, keys, values) -> Table:
         return Table(self, kind, keys, values)
+
+    def selftest_streams(self, triples, philox_counters=None, philox_keys=None) -> dict:
+        """Raw integer streams from the GPU (include/mcx.h: mcx_selftest_streams). triples: uint32 [n, 3] of
+        (seed, idx, iter); philox_counters uint32 [m, 4], philox_keys uint32 [m, 2]."""
+        t = np.ascontiguousarray(triples, dtype=np.uint32).reshape(-1, 3)
+        n = len(t)
+        pc = np.ascontiguousarray(philox_counters if philox_counters is not None else np.zeros((0, 4)), dtype=np.uint32).reshape(-1, 4)
+        pk = np.ascontiguousarray(philox_keys if philox_keys is not None else np.zeros((0, 2)), dtype=np.uint32).reshape(-1, 2)
+        if len(pc) != len(pk):
+            raise ValueError("one key per Philox counter")
+        out = {name: np.zeros(max(n, 1), dtype=np.uint32) for name in ("combined", "hash", "stepped", "angle")}
+        u = np.zeros(max(n, 1), dtype=np.float32)
+        po = np.zeros((max(len(pc), 1), 4), dtype=np.uint32)
+        u32p = C.POINTER(C.c_uint32)
+        ptr = lambda a: a.ctypes.data_as(u32p)
+        check(load().mcx_selftest_streams(self._h, n, ptr(t), ptr(out["combined"]), ptr(out["hash"]), ptr(out["stepped"]),
+                                          ptr(out["angle"]), u.ctypes.data_as(C.POINTER(C.c_float)), len(pc), ptr(pc), ptr(pk),
+                                          ptr(po)))
+        res = {k: v[:n] for k, v in out.items()}
+        res["u"] = u[:n]
+        res["philox"] = po[:len(pc)]
+        return res
 
     def set_target_threads(self, n: int) -> None:
         check(load().mcx_engine_set_target_threads(self._h, int(n)))
@@ -407,7 +474,8 @@ class Engine:
     def last_launch(self) -> dict:
         nb, b, lds = C.c_uint32(), C.c_uint32(), C.c_uint32()
         check(load().mcx_engine_last_launch(self._h, C.byref(nb), C.byref(b), C.byref(lds)))
-        return dict(n_blocks=nb.value, block=b.value, lds_bytes=lds.value)
+        return dict(n_blocks=nb.value, block=b.value, lds_bytes=lds.value,
+                    launches=int(load().mcx_engine_last_launch_count(self._h)))
 
     @staticmethod
     def _ptr(t: Optional[Table]):
@@ -498,6 +566,64 @@ def mcmc_multi(shards, n_steps: int, n_chains: int, n_burnin: int, seed: int, pa
                           float(param1), float(param2), r, n, Engine._ptr(tb.get("cdf")), Engine._ptr(tb.get("target_logpdf")),
                           Engine._ptr(tb.get("proposal_logpdf")), float(x0), float(target_accept))
     return _multi("mcx_mcmc_multi", shards, make, McmcParams)
+
+
+class Comm:
+    """RCCL communicator over the devices of several engines, driven by one host thread (include/mcx.h:
+    mcx_comm_create). shards as for integrate_multi: [(Engine, Module, tables-dict)], one per distinct device."""
+
+    def __init__(self, engines):
+        self._engines = list(engines)
+        n = len(self._engines)
+        self._h = C.c_void_p()
+        arr = (C.c_void_p * n)(*[e._h for e in self._engines])
+        check(load().mcx_comm_create(arr, n, C.byref(self._h)))
+
+    @property
+    def size(self) -> int:
+        return int(load().mcx_comm_size(self._h))
+
+    def _call(self, fn_name, shards, params, ptype):
+        n = len(shards)
+        if [eng for eng, _, _ in shards] != self._engines:
+            raise ValueError("shards must use the communicator's engines, in order")
+        modules = (C.c_void_p * n)(*[mod._h for _, mod, _ in shards])
+        pptr = (C.POINTER(ptype) * n)(*[C.pointer(p) for p in params])
+        sums = np.zeros(result_rows(shards[0][1].desc), dtype=np.float64)
+        n_eff = C.c_uint64(0)
+        check(getattr(load(), fn_name)(self._h, modules, pptr, sums.ctypes.data_as(C.POINTER(C.c_double)), C.byref(n_eff)))
+        return sums, int(n_eff.value)
+
+    def integrate(self, shards, n_samples: int, seed: int, param1: float, param2: float, target_threads: Optional[int] = None):
+        n = len(shards)
+        params = [IntegrateParams(int(n_samples), int(target_threads or 0), int(seed) & 0xFFFFFFFF, float(param1), float(param2),
+                                  r, n, Engine._ptr(tb.get("cdf")), Engine._ptr(tb.get("target_pdf")),
+                                  Engine._ptr(tb.get("proposal_pdf"))) for r, (_, _, tb) in enumerate(shards)]
+        return self._call("mcx_integrate_comm", shards, params, IntegrateParams)
+
+    def mcmc(self, shards, n_steps: int, n_chains: int, n_burnin: int, seed: int, param1: float, param2: float,
+             target_threads: Optional[int] = None, x0: float = 0.0, target_accept: float = 0.44):
+        n = len(shards)
+        params = [McmcParams(int(n_steps), int(n_chains), int(n_burnin), int(target_threads or 0), int(seed) & 0xFFFFFFFF,
+                             float(param1), float(param2), r, n, Engine._ptr(tb.get("cdf")), Engine._ptr(tb.get("target_logpdf")),
+                             Engine._ptr(tb.get("proposal_logpdf")), float(x0), float(target_accept))
+                  for r, (_, _, tb) in enumerate(shards)]
+        return self._call("mcx_mcmc_comm", shards, params, McmcParams)
+
+    def close(self) -> None:
+        if self._h:
+            load().mcx_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def rccl_library() -> str:
+    return (load().mcx_rccl_library() or b"").decode()
 
 
 atexit.register(Engine.close_shared)
