@@ -166,6 +166,10 @@ typedef struct mcx_module_desc {
                                 * pdf_proposal_from_table(x) (src/distribution.rs:181-223, python/wgpu_montecarlo/
                                 * __init__.py:968-974). For callers that hand over the reference's WGSL text unchanged
                                 * (wgpu_montecarlo/_core.py); the package's own API uses the weight mode instead. */
+    int32_t logpdf_analytic;   /* MCMC modules: bit 0 / bit 1 = the target / proposal log-density is the device function
+                                * `mcx_logpdf_p` / `mcx_logpdf_q` (float -> float) of user_src instead of a table -- the reference's fallback
+                                * when `_core.integrate_mcmc` gets no table (src/shader_gen.rs:327-339, 496-509, 543-571).
+                                * The matching mcx_mcmc_params table pointer is then ignored. Not with q_sampler. */
 } mcx_module_desc;
 
 #define MCX_RNG_PCG_REF 0
@@ -258,8 +262,8 @@ typedef struct mcx_mcmc_params {
     float    param1, param2;     /* proposal parameters */
     uint32_t rank, world;
     const mcx_table* cdf;              /* custom proposal */
-    const mcx_table* target_logpdf;    /* MCX_TABLE_LOGPDF, required */
-    const mcx_table* proposal_logpdf;  /* MCX_TABLE_LOGPDF, required unless desc.q_sampler */
+    const mcx_table* target_logpdf;    /* MCX_TABLE_LOGPDF, required unless desc.logpdf_analytic & 1 */
+    const mcx_table* proposal_logpdf;  /* MCX_TABLE_LOGPDF, required unless desc.q_sampler or desc.logpdf_analytic & 2 */
     float    x0;                 /* random-walk modules: chains start at x0 + d_0 (d_0 = the iter-0 draw); else ignored */
     float    target_accept;      /* MCX_WALK_ADAPTIVE: acceptance rate the step scale is tuned towards (0 < a < 1) */
 } mcx_mcmc_params;

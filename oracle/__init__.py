@@ -51,7 +51,7 @@ class _McmcArgs(C.Structure):
                 ("cdf_table", C.POINTER(C.c_float)), ("x_table", C.POINTER(C.c_float)),
                 ("target_logpdf", C.POINTER(C.c_float)), ("proposal_logpdf", C.POINTER(C.c_float)),
                 ("guard", C.c_int32), ("rng", C.c_int32), ("walk", C.c_int32), ("x0", C.c_float),
-                ("target_accept", C.c_float)]
+                ("target_accept", C.c_float), ("target_type", C.c_int32), ("target_p1", C.c_float), ("target_p2", C.c_float)]
 
 
 _lib = None
@@ -223,7 +223,7 @@ def samples(dist_type, param1=0.0, param2=1.0, n_samples=1_000_000, seed=42, cdf
 
 def mcmc(fns, proposal_type, param1, param2, target_x, target_logpdf, proposal_x, proposal_logpdf,
          n_steps=1000, n_chains=256, n_burnin=100, seed=42, cdf_table=None, x_table=None,
-         target_threads=None, guard=0, trace_chains=0, rng=0, walk=0, x0=0.0, target_accept=0.44):
+         target_threads=None, guard=0, trace_chains=0, rng=0, walk=0, x0=0.0, target_accept=0.44, target_analytic=None):
     """Restated K3. Returns dict(ref, sums (K+1, last = accepted steps), n_eff, trace, sumsq (K), chain_mean_sq (K)).
     walk: 0 independent proposals (the reference), 1 / 2 / 3 libmcx's random-walk extensions (general / symmetric /
     adaptive symmetric with step-scale tuning towards target_accept during burn-in)."""
@@ -236,9 +236,13 @@ def mcmc(fns, proposal_type, param1, param2, target_x, target_logpdf, proposal_x
     cdf_table = _f32(cdf_table); x_table = _f32(x_table)
     a.table_size = 0 if cdf_table is None else len(cdf_table)
     a.cdf_table, a.x_table = _fp(cdf_table), _fp(x_table)
-    tl = interleave(target_x, target_logpdf)
-    pl = interleave(proposal_x, proposal_logpdf)
+    # a table given as None selects the reference's analytic log-density (shader_gen.rs:543-571): the target's from
+    # target_analytic = (dist_type, p1, p2), the proposal's from (proposal_type, param1, param2)
+    tl = interleave(target_x, target_logpdf) if target_x is not None else None
+    pl = interleave(proposal_x, proposal_logpdf) if proposal_x is not None else None
     a.target_logpdf, a.proposal_logpdf = _fp(tl), _fp(pl)
+    if tl is None:
+        a.target_type, a.target_p1, a.target_p2 = int(target_analytic[0]), float(target_analytic[1]), float(target_analytic[2])
     a.guard = int(guard)
     a.rng = int(rng)
     a.walk, a.x0, a.target_accept = int(walk), float(x0), float(target_accept)

@@ -368,7 +368,29 @@ typedef struct {
     float    target_accept;        /* walk == 3 (libmcx's adaptive symmetric random walk): x' = x + s d with a per-chain
                                     * scale s = exp(l), l = 0 at the start, l += t^-1/2 (accepted - target_accept) after
                                     * burn-in step t, frozen for the sampling steps */
+    /* Analytic log-densities, used where the matching table pointer is NULL (shader_gen.rs:327-339, 496-509 with
+     * generate_log_pdf_code_for_dist, :543-571): the target from (target_type, target_p1, target_p2), the proposal from
+     * (proposal_type, param1, param2). The reference's Python half always passes tables; this is the `_core` fallback. */
+    int32_t  target_type;
+    float    target_p1, target_p2;
 } orc_mcmc_args;
+
+/* generate_log_pdf_code_for_dist, shader_gen.rs:543-571. (The normal case is pow(z, 2.0) in WGSL, whose result for
+ * z < 0 is backend-defined; restated as the intended z^2, which C's powf returns.) */
+static float orc_logpdf_analytic(int type, float p1, float p2, float x) {
+    if (type == ORC_DIST_UNIFORM) return (p1 <= x && x < p2) ? -logf(p2 - p1) : -100.0f;
+    if (type == ORC_DIST_NORMAL) return -0.5f * powf((x - p1) / p2, 2.0f) - logf(p2 * 2.50662827463f);
+    if (type == ORC_DIST_EXPONENTIAL) return (x >= 0.0f) ? logf(p1) - p1 * x : -100.0f;
+    return -100.0f;
+}
+static float mcmc_logp(const orc_mcmc_args* a, float x) {
+    return a->target_logpdf ? orc_table_lookup(a->target_logpdf, x, -100.0f)
+                            : orc_logpdf_analytic(a->target_type, a->target_p1, a->target_p2, x);
+}
+static float mcmc_logq(const orc_mcmc_args* a, float x) {
+    return a->proposal_logpdf ? orc_table_lookup(a->proposal_logpdf, x, -100.0f)
+                              : orc_logpdf_analytic(a->proposal_type, a->param1, a->param2, x);
+}
 
 /* Philox stream of libmcx for K3: one call per two steps, (idx, it >> 1, 1, 0), key (seed, 'MCX1'). Step `it` takes
  * half h = it & 1: normal proposal z0 (h = 0) / z1 (h = 1) of the Box-Muller pair from outputs (0, 1), any other
@@ -428,7 +450,7 @@ int orc_mcmc(const orc_mcmc_args* a, const orc_fn* fns, int K, float* out_ref, d
         float current_x = a->rng == 1 ? mcmc_sample_q_philox(a, idx, 0u, NULL)
                                       : mcmc_sample_q(a, &bm, idx, 0u);         /* shader_gen.rs:445-463 */
         if (a->walk) current_x += a->x0;
-        float current_log_p = orc_table_lookup(a->target_logpdf, current_x, -100.0f);
+        float current_log_p = mcmc_logp(a, current_x);
         uint64_t accepted = 0;
         float log_s = 0.0f, scale = 1.0f;
         float acc[64];
@@ -440,15 +462,15 @@ int orc_mcmc(const orc_mcmc_args* a, const orc_fn* fns, int K, float* out_ref, d
             float draw = a->rng == 1 ? mcmc_sample_q_philox(a, idx, it, &accept_hash)
                                      : mcmc_sample_q(a, &bm, idx, it + 1000000u);         /* shader_gen.rs:477-489 */
             float proposal_x = a->walk == 3 ? fmaf(scale, draw, current_x) : (a->walk ? current_x + draw : draw);
-            float proposal_log_p_target = orc_table_lookup(a->target_logpdf, proposal_x, -100.0f);
+            float proposal_log_p_target = mcmc_logp(a, proposal_x);
             float log_alpha;
             if (a->walk == 0) {
-                float proposal_log_q = orc_table_lookup(a->proposal_logpdf, proposal_x, -100.0f);
-                float current_log_q = orc_table_lookup(a->proposal_logpdf, current_x, -100.0f);
+                float proposal_log_q = mcmc_logq(a, proposal_x);
+                float current_log_q = mcmc_logq(a, current_x);
                 log_alpha = proposal_log_p_target + current_log_q - current_log_p - proposal_log_q;   /* shader_gen.rs:526 */
             } else if (a->walk == 1) {
-                float lq_fwd = orc_table_lookup(a->proposal_logpdf, draw, -100.0f);
-                float lq_back = orc_table_lookup(a->proposal_logpdf, -draw, -100.0f);
+                float lq_fwd = mcmc_logq(a, draw);
+                float lq_back = mcmc_logq(a, -draw);
                 log_alpha = proposal_log_p_target + lq_back - current_log_p - lq_fwd;
             } else {                                   /* walk 2 and 3: symmetric increments */
                 log_alpha = proposal_log_p_target - current_log_p;

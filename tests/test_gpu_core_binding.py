@@ -95,6 +95,116 @@ def test_integrate_mcmc_payload(core, integrator):
     assert abs(got[0]) < 0.1 and abs(got[1] - 5.0) < 0.2
 
 
+def _golden_calls():
+    import json
+    from pathlib import Path
+
+    gdir = Path(__file__).resolve().parent / "golden"
+    meta = json.loads((gdir / "boundary_payloads.json").read_text())
+    arrays = np.load(gdir / "boundary_payloads.npz")
+    calls = []
+    for entry in meta:
+        args = []
+        for a in entry["args"]:
+            if isinstance(a, dict) and "array" in a:
+                args.append(arrays[a["array"]])
+            elif isinstance(a, dict) and "wgsl" in a:
+                args.append(list(a["wgsl"]))
+            else:
+                args.append(a)
+        calls.append((entry["method"], args))
+    return calls
+
+
+ORC_DIST = {"normal": oracle.NORMAL, "uniform": oracle.UNIFORM, "exponential": oracle.EXPONENTIAL, "custom": oracle.CUSTOM}
+
+
+def test_replay_of_the_payloads_the_reference_emitted(core):
+    """tests/golden/boundary_payloads.{json,npz} hold what the REFERENCE's own Python half handed to `_core` for the
+    BASELINE configs (captured by tools/make_golden.py with a recorder in place of the native module): the WGSL
+    strings its transpiler and its importance-sampling wrapper generator emitted (python/wgpu_montecarlo/
+    __init__.py:893-905, 968-980; names and const order normalised), the parameter dicts and the float32 tables.
+    They are replayed VERBATIM through this package's `_core` (sizes reduced to what the oracle covers in seconds)
+    and the float32[K] results are held to the oracle on the same stream."""
+    calls = _golden_calls()
+    assert [m for m, _ in calls] == ["integrate", "integrate", "integrate_is_tables", "integrate_mcmc", "integrate", "integrate"]
+    pows = lambda k: [(oracle.FN_IDENTITY, 0)] + [(oracle.FN_POW, j) for j in range(2, k + 1)]
+    s2pi = float(np.float32(2.5066282746310002))
+
+    # C1 / C2: integrate(functions, 'normal', {...}, n, seed, None, None, None)
+    for idx, n in ((0, 1_000_000), (1, 3_000_000)):
+        fns, dist, params, _, seed, *rest = calls[idx][1]
+        got = core.integrate(fns, dist, params, n, seed, *rest)
+        ref = oracle.integrate(pows(len(fns)), ORC_DIST[dist], params["mean"], params["std"], n_samples=n, seed=seed, guard=1)
+        assert got.dtype == np.float32 and np.allclose(got, ref["sums"] / ref["n_eff"], rtol=2e-5, atol=2e-5), (idx, got)
+
+    # C3: integrate_is_tables(functions, 'normal', params, n, seed, None, None, target_x, target_pdf, None, None, None)
+    fns, dist, params, _, seed, x_t, cdf_t, tx, tp, px, pp, tt = calls[2][1]
+    assert all("pdf_target_from_table(x)" in f and "_is_pdf_q_" in f for f in fns) and px is None and pp is None
+    got = core.integrate_is_tables(fns, dist, params, 2_000_000, seed, x_t, cdf_t, tx, tp, px, pp, tt)
+    ref = oracle.integrate(pows(4), oracle.NORMAL, 2.0, 3.0, n_samples=2_000_000, seed=seed, guard=1,
+                           p=(oracle.PDF_TABLE, tx, tp), q=(oracle.PDF_NORMAL, 2.0, 3.0, s2pi))
+    assert np.allclose(got, ref["sums"] / ref["n_eff"], rtol=2e-5, atol=2e-5), got
+
+    # C4: integrate_mcmc(functions, 'normal', {...}, 'custom', {...}, n_steps, n_chains, n_burnin, seed, None, None, 4 tables, None)
+    fns, pd, pp_, td, tp_, n_steps, n_chains, n_burnin, seed, x_t, cdf_t, tx, tl, px, pl, tt = calls[3][1]
+    assert (n_steps, n_chains, n_burnin) == (10_000, 1_048_576, 1000) and len(tx) == len(px) == 2048
+    got = core.integrate_mcmc(fns, pd, pp_, td, tp_, 1500, 1000, 100, seed, x_t, cdf_t, tx, tl, px, pl, tt)
+    ref = oracle.mcmc(pows(2), oracle.NORMAL, pp_["mean"], pp_["std"], tx, tl, px, pl, n_steps=1500, n_chains=1000, n_burnin=100,
+                      seed=seed, guard=1)
+    assert np.allclose(got, ref["sums"][:2] / ref["n_eff"], rtol=2e-4, atol=2e-4), got
+
+    # C5's sampler: integrate(functions, 'custom', {...}, n, seed, x_table, cdf_table, None) -- 2048-point Beta(2,5) tables
+    fns, dist, params, _, seed, x_t, cdf_t, tt = calls[4][1]
+    got = core.integrate(fns, dist, params, 3_000_000, seed, x_t, cdf_t, tt)
+    ref = oracle.integrate(pows(2), oracle.CUSTOM, 0.0, 0.0, n_samples=3_000_000, seed=seed, guard=1, cdf_table=cdf_t, x_table=x_t)
+    assert np.allclose(got, ref["sums"] / ref["n_eff"], rtol=2e-5, atol=2e-5), got
+    assert abs(got[0] - 2 / 7) < 1e-3
+
+    # analytic / analytic importance sampling: both PDFs arrive as WGSL text inside the wrapper
+    fns, dist, params, n, seed, *rest = calls[5][1]
+    assert "_is_pdf_p_0" in fns[0] and "_is_pdf_q_0" in fns[0]
+    got = core.integrate(fns, dist, params, 2_000_000, seed, *rest)
+    ref = oracle.integrate(pows(1), oracle.NORMAL, 0.5, 1.5, n_samples=2_000_000, seed=seed, guard=1,
+                           p=(oracle.PDF_NORMAL, 0.0, 1.0, s2pi), q=(oracle.PDF_NORMAL, 0.5, 1.5, s2pi))
+    assert np.allclose(got, ref["sums"] / ref["n_eff"], rtol=2e-5, atol=2e-5), got
+
+
+@pytest.mark.parametrize("case", ["normal|normal", "exponential|exponential", "uniform|normal", "table|normal", "normal|table"])
+def test_integrate_mcmc_without_tables_uses_the_analytic_log_densities(core, case):
+    """The four log-PDF tables of `_core.integrate_mcmc` are optional (src/lib.rs:296-304): without one the MH step
+    evaluates generate_log_pdf_code_for_dist's expression for that distribution type (src/shader_gen.rs:543-571,
+    -100 outside the support). Held to the oracle's restatement of the same fallback, same stream."""
+    from wgpu_montecarlo import Distribution
+
+    fns = ["fn f(x: f32) -> f32 { return x; }", "fn g(x: f32) -> f32 { return x * x; }"]
+    orc_fns = [(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2)]
+    tgt, prop = case.split("|")
+    t_args = dict(normal=("normal", {"mean": 0.3, "std": 1.0}, (oracle.NORMAL, 0.3, 1.0)),
+                  exponential=("exponential", {"lambda": 1.5}, (oracle.EXPONENTIAL, 1.5, 0.0)),
+                  uniform=("uniform", {"min": -1.0, "max": 2.0}, (oracle.UNIFORM, -1.0, 2.0)),
+                  table=("normal", {"mean": 0.3, "std": 1.0}, None))[tgt]
+    p_args = dict(normal=("normal", {"mean": 0.0, "std": 2.0}, oracle.NORMAL, 0.0, 2.0),
+                  exponential=("exponential", {"lambda": 0.7}, oracle.EXPONENTIAL, 0.7, 0.0),
+                  table=("normal", {"mean": 0.0, "std": 2.0}, oracle.NORMAL, 0.0, 2.0))[prop]
+    tx = tl = px = pl = None
+    if tgt == "table":
+        tx, tl = Distribution.normal(0.3, 1.0).get_log_pdf_table()
+    if prop == "table":
+        px, pl = Distribution.normal(0.0, 2.0).get_log_pdf_table()
+    got = core.integrate_mcmc(fns, p_args[0], p_args[1], t_args[0], t_args[1], 1200, 1000, 100, 17, None, None, tx, tl, px, pl, None)
+    ref = oracle.mcmc(orc_fns, p_args[2], p_args[3], p_args[4], tx, tl, px, pl, n_steps=1200, n_chains=1000, n_burnin=100, seed=17,
+                      guard=1, target_analytic=t_args[2])
+    assert np.all(np.isfinite(got))
+    assert np.allclose(got, ref["sums"][:2] / ref["n_eff"], rtol=2e-4, atol=2e-4), (case, got, ref["sums"][:2] / ref["n_eff"])
+    truth = dict(normal=(0.3, 1.09), exponential=(1 / 1.5, 2 / 1.5**2), uniform=(0.5, 1.0), table=(0.3, 1.09))[tgt]
+    assert abs(got[0] - truth[0]) < 0.02 and abs(got[1] - truth[1]) < 0.05
+    if tgt == "table" or prop == "table":
+        return
+    with pytest.raises(RuntimeError, match="custom distribution needs its log-PDF table"):
+        core.integrate_mcmc(fns, "normal", {}, "custom", {"table_size": 8}, 10, 256, 0, 1)
+
+
 def test_error_mapping(core):
     with pytest.raises(ValueError, match="At least one function"):
         core.integrate([], "normal", {}, 1000, 1)

@@ -92,7 +92,7 @@ def transpiler():
         try:
             text = ref.transpile_function(fn)
             text = re.sub(r"user_func_[0-9a-f]{8}", "user_func_XXXXXXXX", text)
-            result[name] = {"ok": True, "wgsl": text}
+            result[name] = {"ok": True, "wgsl": sort_const_runs(text)}
         except ref.TranspilerError as exc:
             result[name] = {"ok": False, "error": str(exc)}
     (GOLDEN / "transpiler_corpus.json").write_text(json.dumps(result, indent=1, sort_keys=True))
@@ -116,6 +116,31 @@ class Recorder:
 
     def integrate_mcmc(self, *a):
         return self._rec("integrate_mcmc", a, len(a[0]))
+
+
+def normalise_wgsl(text: str) -> str:
+    """Make an emitted WGSL string reproducible: the transpiler names lambdas user_func_<uuid8> (transpiler.py:522)
+    and emits captured constants in set-iteration order (transpiler.py:259-269). Names are numbered in order of
+    first appearance; runs of consecutive `const` lines are sorted. Nothing else is touched."""
+    names = {}
+
+    def stable(m):
+        return names.setdefault(m.group(0), f"user_func_{len(names):08x}")
+
+    return sort_const_runs(re.sub(r"user_func_[0-9a-f]{8}", stable, text))
+
+
+def sort_const_runs(text: str) -> str:
+    out, run = [], []
+    for line in text.split("\n"):
+        if line.strip().startswith("const "):
+            run.append(line)
+            continue
+        out += sorted(run)
+        run = []
+        out.append(line)
+    out += sorted(run)
+    return "\n".join(out)
 
 
 def boundary_payloads():
@@ -147,7 +172,9 @@ def boundary_payloads():
             elif isinstance(a, list):
                 entry["args"].append({"n_functions": len(a),
                                       "uses_table_p": any("pdf_target_from_table" in s for s in a),
-                                      "uses_table_q": any("pdf_proposal_from_table" in s for s in a)})
+                                      "uses_table_q": any("pdf_proposal_from_table" in s for s in a),
+                                      # the WGSL strings exactly as the reference's Python half handed them to _core
+                                      "wgsl": [normalise_wgsl(s) for s in a]})
             elif isinstance(a, dict):
                 entry["args"].append({k: (list(v) if isinstance(v, tuple) else v) for k, v in a.items()})
             else:

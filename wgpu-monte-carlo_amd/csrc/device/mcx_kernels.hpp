@@ -450,6 +450,20 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 #define MCX_MCMC_ROWS0 (MCX_K + 1)
 #endif
 #define MCX_MCMC_ROWS (MCX_MCMC_ROWS0 + (MCX_WALK == 3 ? 1 : 0))     // adaptive walk: + the sum of the final step scales
+#ifndef MCX_LOGPDF_ANALYTIC
+#define MCX_LOGPDF_ANALYTIC 0          // bit 0 / 1: target / proposal log-density from mcx_logpdf_p / mcx_logpdf_q (user_src)
+#endif
+// log p / log q of the MH step (shader_gen.rs:327-339, 496-509): from the staged table, or the emitted analytic form
+#if MCX_LOGPDF_ANALYTIC & 1
+#define MCX_LOGP(tb, x) mcx_b2f(mcx_logpdf_p(x))
+#else
+#define MCX_LOGP(tb, x) mcx_table_lookup(tb, x, -100.0f)
+#endif
+#if MCX_LOGPDF_ANALYTIC & 2
+#define MCX_LOGQ(tb, x) mcx_b2f(mcx_logpdf_q(x))
+#else
+#define MCX_LOGQ(tb, x) mcx_table_lookup(tb, x, -100.0f)
+#endif
 #ifndef MCX_PROP_ITER_OFFSET
 #define MCX_PROP_ITER_OFFSET 1000000u      // shader_gen.rs:477-489
 #endif
@@ -479,7 +493,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     McxTable cdf_tb = mcx_stage_table(a.cdf, lds_off);
     McxTable lp_tb = mcx_stage_table(a.target_logpdf, lds_off);
     McxTable lq_tb = mcx_stage_table(a.proposal_logpdf, lds_off);
-    (void)cdf_tb; (void)lq_tb;
+    (void)cdf_tb; (void)lq_tb; (void)lp_tb;
     __syncthreads();
 
     // chain_count is a multiple of 256, so a wave is entirely inside or outside the launch's chain range
@@ -540,7 +554,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #if MCX_WALK
     cur_x += a.x0;                                            // chains start at x0 + d_0
 #endif
-    float cur_lp = mcx_table_lookup(lp_tb, cur_x, -100.0f);
+    float cur_lp = MCX_LOGP(lp_tb, cur_x);
 #if MCX_WALK == 0
 #if MCX_Q_SAMPLER
     // normal proposal: log q(x) = -z^2/2 - log(std sqrt(2 pi)) for the deviate z behind x; the constant cancels in
@@ -548,7 +562,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     // beyond 7 std, which a draw reaches with probability 2.6e-12.)
     float cur_lq = -0.5f * z_init * z_init;
 #else
-    float cur_lq = mcx_table_lookup(lq_tb, cur_x, -100.0f);   // pure function of cur_x: cached
+    float cur_lq = MCX_LOGQ(lq_tb, cur_x);   // pure function of cur_x: cached
 #endif
 #endif
 #if MCX_RNG == 0
@@ -615,31 +629,31 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #endif
 #if MCX_WALK == 0
         const float prop_x = draw;
-        float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
+        float prop_lp = MCX_LOGP(lp_tb, prop_x);
 #if MCX_Q_SAMPLER
         float prop_lq = -0.5f * zd * zd;
 #else
-        float prop_lq = mcx_table_lookup(lq_tb, prop_x, -100.0f);
+        float prop_lq = MCX_LOGQ(lq_tb, prop_x);
 #endif
         mh_finish(it, prop_x, prop_lp, prop_lq, prop_lp + cur_lq - cur_lp - prop_lq, ha);   // shader_gen.rs:526
 #elif MCX_WALK == 1
         const float prop_x = cur_x + draw;
-        float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
+        float prop_lp = MCX_LOGP(lp_tb, prop_x);
 #if MCX_Q_SAMPLER
         // d = m + s z: log q(-d) - log q(d) = (z^2 - (z + 2m/s)^2) / 2 = -(2m/s) (z + m/s)
         mh_finish(it, prop_x, prop_lp, 0.0f, prop_lp - cur_lp - (2.0f * rw_ms) * (zd + rw_ms), ha);
 #else
-        float lq_fwd = mcx_table_lookup(lq_tb, draw, -100.0f);                     // q(x' | x) = q(d)
-        float lq_back = mcx_table_lookup(lq_tb, -draw, -100.0f);                   // q(x | x') = q(-d)
+        float lq_fwd = MCX_LOGQ(lq_tb, draw);                     // q(x' | x) = q(d)
+        float lq_back = MCX_LOGQ(lq_tb, -draw);                   // q(x | x') = q(-d)
         mh_finish(it, prop_x, prop_lp, 0.0f, prop_lp + lq_back - cur_lp - lq_fwd, ha);
 #endif
 #elif MCX_WALK == 2
         const float prop_x = cur_x + draw;
-        float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
+        float prop_lp = MCX_LOGP(lp_tb, prop_x);
         mh_finish(it, prop_x, prop_lp, 0.0f, prop_lp - cur_lp, ha);
 #else
         const float prop_x = fmaf(ad_scale, draw, cur_x);
-        float prop_lp = mcx_table_lookup(lp_tb, prop_x, -100.0f);
+        float prop_lp = MCX_LOGP(lp_tb, prop_x);
         mh_finish(it, prop_x, prop_lp, 0.0f, prop_lp - cur_lp, ha);
 #endif
     };

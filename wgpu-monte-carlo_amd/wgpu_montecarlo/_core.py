@@ -45,6 +45,24 @@ def _params(dist_type: str, params: dict):
     return _DIST[dist_type], 0.0, 0.0
 
 
+def _analytic_logpdf(name: str, code: int, p1: float, p2: float) -> str:
+    """HIP text of the reference's analytic log-density for one distribution type, generate_log_pdf_code_for_dist
+    (src/shader_gen.rs:543-571): what its MH step evaluates when `_core.integrate_mcmc` is given no table. The normal
+    case is `pow(z, 2.0)` in the reference's WGSL -- backend-defined for z < 0 -- and is emitted as the intended z * z."""
+    a, b = repr(float(np.float32(p1))) + "f", repr(float(np.float32(p2))) + "f"
+    if code == runtime.DIST_UNIFORM:
+        body = f"(({a} <= x) && (x < {b})) ? -logf({b} - {a}) : -100.0f"
+    elif code == runtime.DIST_NORMAL:
+        body = f"-0.5f * (((x - {a}) / {b}) * ((x - {a}) / {b})) - logf({b} * 2.50662827463f)"
+    elif code == runtime.DIST_EXPONENTIAL:
+        body = f"(x >= 0.0f) ? logf({a}) - {a} * x : -100.0f"
+    else:
+        # a custom distribution without its table: the reference would emit a call to a lookup function that is not
+        # bound (shader_gen.rs:566-569 / SURVEY.md App. C-8) and fail at pipeline creation
+        raise RuntimeError("Failed to create MCMC pipeline: a custom distribution needs its log-PDF table")
+    return f"MCX_DEV float {name}(float x) {{ return {body}; }}"
+
+
 def _f32(a) -> Optional[np.ndarray]:
     """numpy inputs are copied as f32; a non-contiguous array silently becomes empty in the reference
     (`as_slice().unwrap_or(&[])`, src/lib.rs:71-77) -- here it is simply made contiguous."""
@@ -117,13 +135,23 @@ class MonteCarloIntegrator:
         if int(n_chains) == 0:
             raise ValueError("n_chains must be positive")                   # src/lib.rs:338-342
         code, p1, p2 = _params(proposal_dist_type, proposal_dist_params)
-        _params(target_dist_type, target_dist_params)                       # validated like the reference, then unused
+        t_code, t1, t2 = _params(target_dist_type, target_dist_params)
         cdf = self._cdf(proposal_dist_type, x_table, cdf_table)
-        if target_x_table is None or target_log_pdf_table is None or proposal_x_table is None or proposal_log_pdf_table is None:
-            raise RuntimeError("Failed to setup MCMC: target and proposal log-PDF tables are required")
-        t = self._engine.cached_table(runtime.TABLE_LOGPDF, _f32(target_x_table), _f32(target_log_pdf_table))
-        q = self._engine.cached_table(runtime.TABLE_LOGPDF, _f32(proposal_x_table), _f32(proposal_log_pdf_table))
-        desc = runtime.make_desc(runtime.KIND_MCMC, len(functions), code, guard_endpoints=True)
+        # the four log-PDF tables are optional (src/lib.rs:296-304): without one, the MH step evaluates the analytic
+        # log-density of that distribution type (src/shader_gen.rs:327-339, 496-509)
+        t = q = None
+        analytic = 0
+        if target_x_table is not None and target_log_pdf_table is not None:
+            t = self._engine.cached_table(runtime.TABLE_LOGPDF, _f32(target_x_table), _f32(target_log_pdf_table))
+        else:
+            src += "\n\n" + _analytic_logpdf("mcx_logpdf_p", t_code, t1, t2)
+            analytic |= 1
+        if proposal_x_table is not None and proposal_log_pdf_table is not None:
+            q = self._engine.cached_table(runtime.TABLE_LOGPDF, _f32(proposal_x_table), _f32(proposal_log_pdf_table))
+        else:
+            src += "\n\n" + _analytic_logpdf("mcx_logpdf_q", code, p1, p2)
+            analytic |= 2
+        desc = runtime.make_desc(runtime.KIND_MCMC, len(functions), code, guard_endpoints=True, logpdf_analytic=analytic)
         mod = self._engine.module(src, desc)
         sums, n_eff = self._engine.mcmc(mod, int(n_steps), int(n_chains), int(n_burnin), int(seed), p1, p2, t, q,
                                         target_threads=target_threads, cdf=cdf)
