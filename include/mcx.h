@@ -170,6 +170,13 @@ typedef struct mcx_module_desc {
                                 * `mcx_logpdf_p` / `mcx_logpdf_q` (float -> float) of user_src instead of a table -- the reference's fallback
                                 * when `_core.integrate_mcmc` gets no table (src/shader_gen.rs:327-339, 496-509, 543-571).
                                 * The matching mcx_mcmc_params table pointer is then ignored. Not with q_sampler. */
+    int32_t cdf_direct;        /* 1 (custom sampling / proposal distribution, not with precise_sampler): the caller guarantees the
+                                * CDF table of every call has the bucket-direct form (mcx_table_has_direct). A draw whose
+                                * bucket (the top bits of its hash word) holds no cdf node is then ONE 8-byte read and one FMA --
+                                * the same cell the reference's lower-bound search selects (src/distribution.rs:128-158), its
+                                * line evaluated on the unrounded low hash bits (<= 2.4e-7 * slope from the blend on the
+                                * rounded u); other draws run the search inside the bucket's window. The integrate kernel
+                                * additionally defers those draws to a per-wave LDS queue and resolves them 64 at a time. */
 } mcx_module_desc;
 
 #define MCX_RNG_PCG_REF 0
@@ -221,6 +228,9 @@ uint32_t mcx_table_lds_bytes(const mcx_table* t);
 /* Host-side: the index map of the cell form, idx = floor(x * scale + c0) clamped to [0, n]: 1 + c is cell c, 0 and n
  * are sentinel cells {outside value, slope 0} for x left / right of the table (both table ends map inside). */
 int  mcx_table_cell_map(const float* keys, uint32_t n, float* scale_out, float* c0_out);
+/* CDF tables: log2 of the number of bucket-direct records the table was stored with, 0 if it has none (non-monotone
+ * cdf or x column, n > 4096). */
+int  mcx_table_has_direct(const mcx_table* t);
 /* 1 if the table was stored with slope-intercept cells (PDF / log-PDF kinds on a strict f32-linspace grid), else 0. */
 int  mcx_table_has_cells(const mcx_table* t);
 int  mcx_table_cells(const float* keys, const float* values, uint32_t n, float* cells_out);

@@ -12,7 +12,10 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-_LIB_PATH = _HERE / "liboracle.so"
+import os as _os
+
+# MCX_ORACLE_LIBRARY selects another build of the same source (tools/sanitize_cpu.sh: the ASan + UBSan build)
+_LIB_PATH = Path(_os.environ["MCX_ORACLE_LIBRARY"]) if _os.environ.get("MCX_ORACLE_LIBRARY") else _HERE / "liboracle.so"
 
 UNIFORM, NORMAL, EXPONENTIAL, CUSTOM = 0, 1, 2, 3
 FN_IDENTITY, FN_POW, FN_SIN, FN_COS, FN_EXP, FN_GT, FN_BENCH, FN_ABS, FN_CONST, FN_SQ = range(10)
@@ -22,6 +25,8 @@ PDF_NONE, PDF_UNIFORM, PDF_NORMAL, PDF_EXPONENTIAL, PDF_TABLE = range(5)
 def build(force: bool = False) -> Path:
     """Compile liboracle.so with gcc if missing (or stale)."""
     src = _HERE / "mcx_oracle.c"
+    if _os.environ.get("MCX_ORACLE_LIBRARY"):
+        return _LIB_PATH
     if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < src.stat().st_mtime:
         subprocess.run(["make", "-C", str(_HERE), "-B", "liboracle.so"], check=True, capture_output=True)
     return _LIB_PATH

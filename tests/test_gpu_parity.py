@@ -432,10 +432,15 @@ def test_large_tables_and_capped_search(integrator, n_prop, n_tgt, in_lds):
     xt = np.linspace(-6, 6, n_tgt)
     target = Distribution.from_pdf_table(xt, np.exp(-0.5 * xt * xt) / np.sqrt(2 * np.pi))
     res = integrator.integrate_importance_sampling([lambda x: x, lambda x: x**2], target, proposal, n_samples=1_000_000, seed=4)
-    # CDF table {cdf, x} + its slopes, proposal PDF table, target PDF table (no guide: n > 4096)
-    guide = 0 if n_prop > 4096 else 4 * 4 * (1 << (n_prop - 1).bit_length())          # G = 4 * pow2ceil(n) entries
-    # (+ 8 bytes per strict-grid PDF table: its cell form carries two sentinel cells)
-    assert res.meta["lds_bytes"] == ((2 * n_prop + n_tgt + 2) * 8 + (n_prop * 4 + 7) // 8 * 8 + guide if in_lds else 0)
+    # staged: the proposal and target PDF tables in cell form ((n + 1) * 8 bytes each: two sentinel cells), and for the
+    # sampling CDF table either its bucket-direct records (n <= 4096: G = 4 * pow2ceil(n) records of 8 bytes, plus
+    # the 16 per-wave queues of 128 words; {cdf, x} and slopes stay in global memory) or, without them (n > 4096: the
+    # capped search), {cdf, x} + slopes
+    if n_prop <= 4096:
+        cdf_bytes = 8 * min(4 * (1 << (n_prop - 1).bit_length()), 8192) + 16 * 128 * 4
+    else:
+        cdf_bytes = n_prop * 8 + (n_prop * 4 + 7) // 8 * 8
+    assert res.meta["lds_bytes"] == ((n_prop + n_tgt + 2) * 8 + cdf_bytes if in_lds else 0)
     ref = oracle.integrate([(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2)], oracle.CUSTOM, n_samples=1_000_000, seed=4, guard=1,
                            cdf_table=proposal._cdf_table, x_table=proposal._x_table,
                            p=(oracle.PDF_TABLE, target._x_table, target._pdf_table),

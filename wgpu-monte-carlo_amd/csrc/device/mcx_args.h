@@ -27,7 +27,8 @@ typedef struct McxTableDesc {
                             // (PDF / log-PDF tables on a strict grid), or null
     const float* slopes;    // device pointer, n inverse-CDF slopes dx/dcdf per cell (CDF tables), or null
     float   cell_scale;
-    mcx_u32 _pad1;
+    mcx_u32 direct_bits;    // CDF tables: log2 of the number of bucket-direct records, 0 = none
+    const float* direct;    // device pointer, 2 floats per bucket: {x_b, slope * 2^-32} or {lo | hi << 16, -0.0f}
 } McxTableDesc;
 
 // K1 / K2: plain and importance-sampling integration.

@@ -181,18 +181,43 @@ MCX_DEV void mcx_box_muller(u32 h1, u32 h2, float& z0, float& z1) {
 #define MCX_CELL_TABLES 0
 #endif
 
+// Pointers into the staged tables carry their address space explicitly: LDS (address space 3) when the module stages
+// its tables (MCX_TABLES_LDS), global otherwise. Left generic, hiprtc's optimiser (ROCm 7.2) fails to infer LDS for
+// pointers that travel through this struct and emits flat_load + 64-bit address arithmetic for every lookup -- which
+// is what the round-1 builds of the table kernels ran (hipcc's newer clang did infer it, so offline ISA looked fine).
+#ifndef MCX_TABLES_LDS
+#define MCX_TABLES_LDS 1
+#endif
+#if MCX_TABLES_LDS
+#define MCX_TBL __attribute__((address_space(3)))
+#else
+#define MCX_TBL
+#endif
 struct McxTable {
-    const float2* kv;     // LDS or global
+    const MCX_TBL float2* kv;     // LDS or global
     u32   n;
     float k0, k1;         // kv[0].x, kv[n-1].x
     float inv_dk;         // (n-1)/(k[n-1]-k[0]) when the keys are a uniform grid, else 0
-    const u32* guide;     // CDF only: guide[b] = lo | hi << 16, the search window of bucket b, or null
+    const MCX_TBL u32* guide;     // CDF only: guide[b] = lo | hi << 16, the search window of bucket b, or null
     u32   guide_bits;     // number of buckets G = 1 << guide_bits
-    const float2* cells;  // PDF / log-PDF on a strict grid: cells[1 + c] = {intercept, slope} of cell c, cells[0] and
+    const MCX_TBL float2* cells;  // PDF / log-PDF on a strict grid: cells[1 + c] = {intercept, slope} of cell c, cells[0] and
                           // cells[n] = {outside, 0} for x left / right of the table; else null (then kv is set)
     float cell_scale, cell_c0;   // padded cell index = floor(x * cell_scale + cell_c0) (host: cell_map)
-    const float* slopes;  // CDF: slopes[c] = dx/dcdf of cell c (0 for cells narrower than 1e-10), or null
+    const MCX_TBL float* slopes;  // CDF: slopes[c] = dx/dcdf of cell c (0 for cells narrower than 1e-10), or null
 };
+
+// A wave-uniform value as a per-lane (VGPR) copy the compiler cannot fold back into an SGPR: on gfx950 a VALU
+// instruction with an SGPR source operand issues at half rate (tools/ubench/valu_issue.hip).
+MCX_DEV float mcx_in_vgpr(float s) {
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+MCX_DEV u32 mcx_in_vgpr_u32(u32 s) {
+    u32 v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
 
 // a / b with v_rcp_f32 (<= 1.5 ulp): used for the interpolation weights and the importance ratio.
 // WGSL only promises 2.5 ulp for f32 division, so this stays inside the reference's own contract.
@@ -207,7 +232,7 @@ MCX_DEV float mcx_div(float a, float b) {
 // First index i in [0, n-1] with key[i] >= q, searching exactly like the reference's capped loop
 // (it never tests index n-1; `cap` = 12 for CDF sampling, 16 for PDF lookup).
 template <int CAP>
-MCX_DEV u32 mcx_lower_bound_capped(const float2* kv, u32 n, float q) {
+MCX_DEV u32 mcx_lower_bound_capped(const MCX_TBL float2* kv, u32 n, float q) {
     u32 low = 0u, high = n - 1u;
 #pragma unroll 1
     for (int j = 0; j < CAP; ++j) {
@@ -230,6 +255,50 @@ MCX_DEV float mcx_mix(float a, float b, float t) {
     return fmaf(t, b - a, a);
 #endif
 }
+
+#ifndef MCX_CDF_DIRECT
+#define MCX_CDF_DIRECT 0
+#endif
+#if MCX_CDF_DIRECT
+// Bucket-direct inverse CDF (host: mcx_plan.cpp build_cdf_direct; integrate kernel, reference stream). The record of
+// the draw's bucket either IS the answer -- the line of the one table cell the whole bucket lies in, the cell the
+// reference's search would select -- or it is flagged (sign bit of .y) and carries the search window [lo, hi] of a
+// bucket that holds cdf nodes. Only the records live in LDS (8 bytes x 8192 buckets for a 2048-point table: two
+// 1024-thread workgroups per CU); the {cdf, x} pairs and slopes the flagged draws need stay in global memory, where
+// 24 KiB of them sit in the CU's L1 / the XCD's L2 -- they are read only by the batched resolve step.
+struct McxCdfDirect {
+    const __attribute__((address_space(3))) float2* rec;   // LDS (global when !MCX_TABLES_LDS: see MCX_REC)
+    const float2* kv;          // global {cdf, x}
+    const float* slopes;       // global dx/dcdf per cell
+    u32 shift, mask;           // per-lane copies (mcx_in_vgpr_u32): bucket = h >> shift, low bits = h & mask
+};
+// The flag test as ONE v_cmp whose SGPR-pair result is the wave's ballot: bit l = lane l's record is flagged. The
+// per-lane predicate is recovered with inverse_ballot (the mask itself becomes the exec mask: no second compare, no
+// v_cndmask / v_cmp_ne round trip). volatile: the compare reads EXEC implicitly and must stay where it is written.
+// hiprtc's clang (ROCm 7.2) has the LLVM intrinsic but not yet the __builtin_amdgcn_inverse_ballot_w64 spelling that
+// hipcc's clang offers: bind the intrinsic by its IR name.
+extern "C" __device__ bool mcx_inverse_ballot(u64 mask) __asm("llvm.amdgcn.inverse.ballot.i64");
+MCX_DEV u64 mcx_cdf_flag_mask(float2 r) {
+    u64 m;
+    asm volatile("v_cmp_gt_i32_e64 %0, 0, %1" : "=s"(m) : "v"(__builtin_bit_cast(int, r.y)));
+    return m;
+}
+// x on the record's line from the low hash bits: (u - b/G) = (h & mask) * 2^-32 exactly. For a flagged record this is
+// ~1e-34 (the packed window read as a float, times -0.0): finite and harmless; the resolve step supplies the sample.
+MCX_DEV float mcx_cdf_line(const McxCdfDirect& cd, float2 r, u32 h) { return fmaf(r.y, (float)(h & cd.mask), r.x); }
+// The reference's lower bound inside the window of a flagged record, then its interpolant in slope form.
+MCX_DEV float mcx_cdf_search_window(const McxCdfDirect& cd, u32 window, float u) {
+    u32 lo = window & 0xFFFFu, hi = window >> 16;
+    while (lo < hi) {
+        u32 mid = (lo + hi) >> 1;
+        if (cd.kv[mid].x < u) lo = mid + 1u; else hi = mid;
+    }
+    const u32 il = __builtin_elementwise_sub_sat(lo, 1u);
+    const float2 a = cd.kv[il];
+    const float d = fminf(fmaxf(u - a.x, 0.0f), 1.0f);
+    return fmaf(cd.slopes[il], d, a.y);
+}
+#endif
 
 // sample_from_cdf_table (distribution.rs:128-158). key = cdf, value = x.
 // h is the hash u = float(h) * 2^-32 was made from.
@@ -289,7 +358,7 @@ MCX_DEV float mcx_lerp_cell(float2 a, float2 b, float x) {
 #ifndef MCX_COLD
 #define MCX_COLD MCX_DEV
 #endif
-MCX_COLD float mcx_table_lookup_cold(const float2* kv, u32 n, float x, int g) {
+MCX_COLD float mcx_table_lookup_cold(const MCX_TBL float2* kv, u32 n, float x, int g) {
     u32 low = 0xFFFFFFFFu;
     if (g >= 0) {
         if (g > 0 && kv[g - 1].x < x && x <= kv[g].x) low = (u32)g - 1u;
@@ -321,7 +390,7 @@ MCX_DEV float2 mcx_cell_fetch(const McxTable& tb, float x) {
 #endif
 
 MCX_DEV float mcx_table_lookup(const McxTable& tb, float x, float outside) {
-    const float2* kv = tb.kv;
+    const MCX_TBL float2* kv = tb.kv;
     const u32 n = tb.n;
     const bool out_of_range = (x < tb.k0) || (x > tb.k1);
 #if MCX_CELL_TABLES

@@ -67,15 +67,29 @@ static constexpr int mcx_unroll = MCX_UNROLL;   // a constant, not the macro, in
 #if MCX_UNIT_PARAMS
 #define MCX_AFFINE(z) (z)
 #else
-// mean + std * z as ONE v_fma_f32: an FMA may read a single scalar operand, so the mean has to sit in a vector
-// register. Left to itself the compiler re-materialises it (v_mov_b32 from the SGPR) in every loop iteration; an
-// opaque copy made once per kernel (`mcx_affine_b`, below) stays in its VGPR.
-#define MCX_AFFINE(z) (mcx_affine_b + a.param2 * (z))
+// mean + std * z as ONE full-rate v_fma_f32. On gfx950 a VALU instruction that reads an SGPR operand issues at HALF
+// rate (4.1 instead of 2.2 cycles per wave-instruction per SIMD; inline constants and literals are free --
+// tools/ubench/valu_issue.hip, profiles/r02_valu_issue_microbench.txt), and an FMA may read only one scalar operand
+// anyway, which the compiler otherwise re-materialises (v_mov_b32 from the SGPR) in every iteration. So every
+// wave-uniform float the hot loops multiply or add with lives in a VGPR: opaque copies made once per kernel (pv).
+#define MCX_AFFINE(z) (pv.p1 + pv.p2 * (z))
 #endif
-MCX_DEV float mcx_in_vgpr(float s) {
-    float v;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
-    return v;
+// The call's distribution parameters (and what the loops derive from them) as per-lane copies of wave-uniform values.
+struct McxParamsV {
+    float p1, p2;        // min / mean / lambda, max / std
+    float inv_p1;        // exponential: 1 / lambda
+    float span;          // uniform: max - min
+    float q_norm;        // q_sampler weights: std * sqrt(2 pi)
+};
+template <class Args>
+MCX_DEV McxParamsV mcx_params_v(const Args& a) {
+    McxParamsV pv;
+    pv.p1 = mcx_in_vgpr(a.param1);
+    pv.p2 = mcx_in_vgpr(a.param2);
+    pv.inv_p1 = mcx_in_vgpr(__builtin_amdgcn_rcpf(a.param1));
+    pv.span = mcx_in_vgpr(a.param2 - a.param1);
+    pv.q_norm = mcx_in_vgpr(a.param2 * 2.5066282746310002f);
+    return pv;
 }
 
 // Large K: per-thread f64 sums would need 2K VGPRs (K = 32 spills). Instead every MCX_FLUSH units each
@@ -101,8 +115,8 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
     t.guide = nullptr;
     t.kv = nullptr;
     t.cells = nullptr;
-    t.cell_c0 = d.cell_c0;
-    t.cell_scale = d.cell_scale;
+    t.cell_c0 = mcx_in_vgpr(d.cell_c0);           // VGPR copies: an SGPR operand would halve the rate of the index FMA
+    t.cell_scale = mcx_in_vgpr(d.cell_scale);
     t.slopes = nullptr;
     t.k0 = 0.0f;
     t.k1 = 0.0f;
@@ -113,20 +127,20 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
     const bool cell_form = false;
 #endif
 #if MCX_TABLES_LDS
-    float2* dst = (float2*)(mcx_lds_raw + off);
+    MCX_TBL float2* dst = (MCX_TBL float2*)(mcx_lds_raw + off);
     const float2* src = (const float2*)(cell_form ? d.cells : d.kv);
     const u32 count = cell_form ? d.n + 1u : d.n;       // cell form: two sentinels + n - 1 cells
     for (u32 i = threadIdx.x; i < count; i += MCX_BLOCK) dst[i] = src[i];
     off += count * 8u;
     if (cell_form) t.cells = dst; else t.kv = dst;
     if (d.slopes != nullptr) {
-        float* sdst = (float*)(mcx_lds_raw + off);
+        MCX_TBL float* sdst = (MCX_TBL float*)(mcx_lds_raw + off);
         for (u32 i = threadIdx.x; i < d.n; i += MCX_BLOCK) sdst[i] = d.slopes[i];
         off += (d.n * 4u + 7u) & ~7u;      // keep the next table's float2 8-byte aligned (same rounding on the host)
         t.slopes = sdst;
     }
     if (d.guide != nullptr) {
-        u32* gdst = (u32*)(mcx_lds_raw + off);
+        MCX_TBL u32* gdst = (MCX_TBL u32*)(mcx_lds_raw + off);
         u32 gn = 1u << d.guide_bits;
         for (u32 i = threadIdx.x; i < gn; i += MCX_BLOCK) gdst[i] = d.guide[i];
         off += gn * 4u;
@@ -141,6 +155,25 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
     t.k1 = d.kv[2u * (d.n - 1u)];
     return t;
 }
+
+#if MCX_CDF_DIRECT
+// Stage the bucket-direct records of the sampling CDF table (the launch guarantees the table has them); its {cdf, x}
+// pairs and slopes are NOT staged (McxCdfDirect). Unconditional code: a pointer that is LDS on every path keeps its
+// address space (ds_read_b64, not flat_load) through hiprtc's optimiser.
+MCX_DEV McxCdfDirect mcx_stage_cdf_direct(const McxTableDesc& d, u32& off) {
+    McxCdfDirect cd;
+    cd.shift = mcx_in_vgpr_u32(32u - d.direct_bits);
+    cd.mask = mcx_in_vgpr_u32((1u << (32u - d.direct_bits)) - 1u);
+    cd.kv = (const float2*)d.kv;
+    cd.slopes = d.slopes;
+    __attribute__((address_space(3))) float2* dst = (__attribute__((address_space(3))) float2*)(mcx_lds_raw + off);
+    const u32 dn = 1u << d.direct_bits;
+    for (u32 i = threadIdx.x; i < dn; i += MCX_BLOCK) dst[i] = ((const float2*)d.direct)[i];
+    off += dn * 8u;
+    cd.rec = dst;
+    return cd;
+}
+#endif
 
 // Fold the per-thread f64 sums of a workgroup and store them as one contiguous record
 // partials[blockIdx.x * N + k] (a single N*8-byte store per workgroup).
@@ -198,18 +231,20 @@ MCX_DEV float mcx_weight(float x, const McxIsTables& tb) {
 // Normal sampler: the sample is x = mean + std * z. With MCX_Q_SAMPLER the importance weight uses
 // 1/q(x) = std * sqrt(2 pi) * exp(z^2 / 2) from the deviate itself -- one v_exp_f32 and three multiplies instead of
 // evaluating the emitted N(mean, std) density at x (subtract, divide, square, exp, scale) and taking its reciprocal.
-template <class Args>
-MCX_DEV float mcx_weight_z(float z, float x, const Args& a, const McxIsTables& tb) {
+MCX_DEV float mcx_weight_z(float z, float x, const McxParamsV& pv, const McxIsTables& tb) {
 #if MCX_WEIGHT && MCX_Q_SAMPLER
 #if MCX_P_TABLE
     const float p = mcx_table_lookup(tb.p, x, 0.0f);
 #else
     const float p = mcx_b2f(mcx_pdf_p(x));
 #endif
-    const float sigma = MCX_UNIT_PARAMS ? 1.0f : a.param2;
-    return p * ((sigma * 2.5066282746310002f) * __builtin_amdgcn_exp2f((z * z) * 0.72134752044448170f));
+#if MCX_UNIT_PARAMS
+    return p * (2.5066282746310002f * __builtin_amdgcn_exp2f((z * z) * 0.72134752044448170f));
 #else
-    (void)z; (void)a;
+    return p * (pv.q_norm * __builtin_amdgcn_exp2f((z * z) * 0.72134752044448170f));
+#endif
+#else
+    (void)z; (void)pv;
     return mcx_weight(x, tb);
 #endif
 }
@@ -219,9 +254,9 @@ template <int S>
 MCX_DEV void mcx_accumulate(float x, const McxIsTables& tb, float* acc) {
     mcx_eval_all<S>(x, mcx_weight(x, tb), acc);
 }
-template <int S, class Args>
-MCX_DEV void mcx_accumulate_z(float z, float x, const Args& a, const McxIsTables& tb, float* acc) {
-    mcx_eval_all<S>(x, mcx_weight_z(z, x, a, tb), acc);
+template <int S>
+MCX_DEV void mcx_accumulate_z(float z, float x, const McxParamsV& pv, const McxIsTables& tb, float* acc) {
+    mcx_eval_all<S>(x, mcx_weight_z(z, x, pv, tb), acc);
 }
 
 // Two samples at once. MCX_MOMENT_FAMILY (user_func_i(x) = x^(i+1), promised by the caller): the generated
@@ -238,25 +273,36 @@ MCX_DEV void mcx_accumulate_pair(float xa, float xb, float wa, float wb, float* 
 }
 
 // One sample of a non-normal distribution from one hash output.
-MCX_DEV float mcx_draw(u32 h, const McxIntegrateArgs& a, const McxTable& cdf_tb) {
+MCX_DEV float mcx_draw(u32 h, const McxParamsV& pv, const McxTable& cdf_tb) {
 #if MCX_DIST == MCX_DIST_UNIFORM
     (void)cdf_tb;
-    return MCX_UNIT_PARAMS ? mcx_u01(h) : mcx_sample_uniform(mcx_u01(h), a.param1, a.param2);
+    return MCX_UNIT_PARAMS ? mcx_u01(h) : fmaf(mcx_u01(h), pv.span, pv.p1);          // min + u (max - min)
 #elif MCX_DIST == MCX_DIST_EXPONENTIAL
     (void)cdf_tb;
-    return mcx_sample_exponential(mcx_u01_closed(h), MCX_UNIT_PARAMS ? 1.0f : a.param1);
+#if MCX_PRECISE_SAMPLER
+    return mcx_sample_exponential(mcx_u01_closed(h), MCX_UNIT_PARAMS ? 1.0f : pv.p1);
 #else
+    // -ln(max(u, 1e-7)) / lambda with the reciprocal of the wave-uniform lambda taken once per kernel
+    const float e = -mcx_native_ln(fmaxf(mcx_u01_closed(h), 1.0e-7f));
+    return MCX_UNIT_PARAMS ? e : e * pv.inv_p1;
+#endif
+#else
+    (void)pv;
     return mcx_sample_cdf(cdf_tb, mcx_u01_closed(h), h);
 #endif
 }
 
 extern "C" __global__ void __launch_bounds__(MCX_BLOCK)
 mcx_integrate_kernel(McxIntegrateArgs a) {
-#if !MCX_UNIT_PARAMS && MCX_DIST == MCX_DIST_NORMAL
-    const float mcx_affine_b = mcx_in_vgpr(a.param1);
-#endif
+    const McxParamsV pv = mcx_params_v(a);
+    (void)pv;
     u32 lds_off = 0u;
+#if MCX_CDF_DIRECT
+    const McxCdfDirect cd = mcx_stage_cdf_direct(a.cdf, lds_off);
+    McxTable cdf_tb = mcx_stage_table(McxTableDesc{}, lds_off);          // nothing else of the CDF table is staged
+#else
     McxTable cdf_tb = mcx_stage_table(a.cdf, lds_off);
+#endif
     McxIsTables is_tb;
     is_tb.p = mcx_stage_table(a.target_pdf, lds_off);
     is_tb.q = mcx_stage_table(a.proposal_pdf, lds_off);
@@ -325,11 +371,11 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 #if MCX_DIST == MCX_DIST_NORMAL
         float z0, z1;
         mcx_box_muller(h_first, h_second, z0, z1);
-        mcx_accumulate_z<MCX_ACC_S>(z0, MCX_AFFINE(z0), a, is_tb, acc);
-        if (n_valid > 1u) mcx_accumulate_z<MCX_ACC_S>(z1, MCX_AFFINE(z1), a, is_tb, acc + (MCX_ACC_S - 1));
+        mcx_accumulate_z<MCX_ACC_S>(z0, MCX_AFFINE(z0), pv, is_tb, acc);
+        if (n_valid > 1u) mcx_accumulate_z<MCX_ACC_S>(z1, MCX_AFFINE(z1), pv, is_tb, acc + (MCX_ACC_S - 1));
 #else
-        mcx_accumulate<MCX_ACC_S>(mcx_draw(h_first, a, cdf_tb), is_tb, acc);
-        if (n_valid > 1u) mcx_accumulate<MCX_ACC_S>(mcx_draw(h_second, a, cdf_tb), is_tb, acc + (MCX_ACC_S - 1));
+        mcx_accumulate<MCX_ACC_S>(mcx_draw(h_first, pv, cdf_tb), is_tb, acc);
+        if (n_valid > 1u) mcx_accumulate<MCX_ACC_S>(mcx_draw(h_second, pv, cdf_tb), is_tb, acc + (MCX_ACC_S - 1));
 #endif
     };
     const u32 full_quads = a.loops_per_thread >> 2;          // calls whose four iterations all exist
@@ -372,7 +418,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
             float z0, z1;
             mcx_box_muller(h1, h2, z0, z1);
             const float xa = MCX_AFFINE(z0), xb = MCX_AFFINE(z1);
-            mcx_accumulate_pair<MCX_ACC_S>(xa, xb, mcx_weight_z(z0, xa, a, is_tb), mcx_weight_z(z1, xb, a, is_tb), acc);
+            mcx_accumulate_pair<MCX_ACC_S>(xa, xb, mcx_weight_z(z0, xa, pv, is_tb), mcx_weight_z(z1, xb, pv, is_tb), acc);
         }
         MCX_FLUSH_ACC();
     }
@@ -384,7 +430,88 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         float z0, z1;
         mcx_box_muller(h1, h2, z0, z1);
         MCX_ZERO_ACC();
-        mcx_accumulate_z<MCX_ACC_S>(z0, MCX_AFFINE(z0), a, is_tb, acc);
+        mcx_accumulate_z<MCX_ACC_S>(z0, MCX_AFFINE(z0), pv, is_tb, acc);
+        MCX_FLUSH_ACC();
+    }
+#elif MCX_CDF_DIRECT
+    // unit = iteration i, counter i (distribution.rs:333). Bucket-direct sampling: a draw whose bucket holds no cdf node
+    // is one 8-byte LDS read + one FMA. The others (17 % on Beta(2,5) at 8192 buckets) would make EVERY wave walk the
+    // search path for a few lanes each iteration; instead their hash words are appended to a per-wave LDS queue
+    // (one v_cmp per sample gives the ballot, mbcnt the slots) and resolved 64 at a time with all lanes busy.
+    // The sum does not care which lane, or which flush block, a sample is added in; every draw of the grid is still
+    // evaluated exactly once. (Measured and not kept: requesting the records of pair p + 1 before evaluating pair p,
+    // and one combined append per pair -- 1.61 ms against 1.59 ms per 2e9 samples at K = 4, and 4 KiB more LDS.)
+#ifndef MCX_QCAP
+#define MCX_QCAP 128u                 // <= 63 left over + 64 appended
+#endif
+    __attribute__((address_space(3))) u32* const queue =
+        (__attribute__((address_space(3))) u32*)(mcx_lds_raw + lds_off) + (threadIdx.x >> 6) * MCX_QCAP;
+    const u32 lane_id = threadIdx.x & 63u;
+    u32 q_count = 0u;                 // wave-uniform
+    // resolve the newest `take` (<= 64) queued draws, one per lane: the reference's search inside the bucket's window
+    auto resolve = [&](u32 take) {
+        __builtin_amdgcn_wave_barrier();
+        if (lane_id < take) {
+            const u32 h = queue[q_count - take + lane_id];
+            const float2 r = cd.rec[h >> cd.shift];
+            const float x = mcx_cdf_search_window(cd, __builtin_bit_cast(u32, r.x), (float)h * 0x1.0p-32f);
+            mcx_accumulate<MCX_ACC_S>(x, is_tb, acc);
+        }
+        q_count -= take;
+        __builtin_amdgcn_wave_barrier();
+    };
+    // append the flagged lanes' hash words (m = their ballot); resolve a full batch as soon as there is one
+    auto defer = [&](u64 m, bool flagged, u32 h) {
+        if (m != 0ull) {              // wave-uniform
+            const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, q_count));
+            if (flagged) queue[pos] = h;
+            q_count += (u32)__builtin_popcountll(m);
+            if (q_count >= 64u) resolve(64u);
+        }
+    };
+    u32 st = mcx_state(a.seed, idx, u0);
+    u32 i = u0;
+    while (i < u1) {
+        u32 blk_end = i + 2u * MCX_FLUSH;
+        blk_end = blk_end < u1 ? blk_end : u1;
+        MCX_ZERO_ACC();
+#pragma unroll mcx_unroll
+        for (; i + 1u < blk_end; i += 2u) {
+            const u32 hA = mcx_pcg_out(st);
+            const u32 hB = mcx_pcg_out(st + MCX_STATE_STEP);
+            st += 2u * MCX_STATE_STEP;
+            const float2 rA = cd.rec[hA >> cd.shift];
+            const float2 rB = cd.rec[hB >> cd.shift];
+            const u64 mA = mcx_cdf_flag_mask(rA), mB = mcx_cdf_flag_mask(rB);
+            const bool fA = mcx_inverse_ballot(mA), fB = mcx_inverse_ballot(mB);
+            const float xA = mcx_cdf_line(cd, rA, hA), xB = mcx_cdf_line(cd, rB, hB);
+#if MCX_MOMENT_FAMILY
+            // a flagged lane's x is ~1e-34 (mcx_cdf_line): its powers add nothing to the power sums, so without weights
+            // the pair needs no masking; with importance weights the flagged sample's weight is forced to 0
+            mcx_accumulate_pair<MCX_ACC_S>(xA, xB, MCX_WEIGHT ? (fA ? 0.0f : mcx_weight(xA, is_tb)) : 1.0f,
+                                           MCX_WEIGHT ? (fB ? 0.0f : mcx_weight(xB, is_tb)) : 1.0f, acc);
+#else
+            if (!fA) mcx_accumulate<MCX_ACC_S>(xA, is_tb, acc);
+            if (!fB) mcx_accumulate<MCX_ACC_S>(xB, is_tb, acc + (MCX_ACC_S - 1));
+#endif
+            defer(mA, fA, hA);
+            defer(mB, fB, hB);
+        }
+        if (i < blk_end) {                                   // odd tail of the block
+            const u32 h = mcx_pcg_out(st);
+            st += MCX_STATE_STEP;
+            ++i;
+            const float2 r = cd.rec[h >> cd.shift];
+            const u64 m = mcx_cdf_flag_mask(r);
+            const bool f = mcx_inverse_ballot(m);
+            if (!f) mcx_accumulate<MCX_ACC_S>(mcx_cdf_line(cd, r, h), is_tb, acc);
+            defer(m, f, h);
+        }
+        MCX_FLUSH_ACC();
+    }
+    if (q_count != 0u) {                                     // what is left in the queue (< 64 draws)
+        MCX_ZERO_ACC();
+        resolve(q_count);
         MCX_FLUSH_ACC();
     }
 #else
@@ -400,12 +527,12 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
             u32 hA = mcx_pcg_out(st);
             u32 hB = mcx_pcg_out(st + MCX_STATE_STEP);
             st += 2u * MCX_STATE_STEP;
-            float xA = mcx_draw(hA, a, cdf_tb);
-            float xB = mcx_draw(hB, a, cdf_tb);
+            float xA = mcx_draw(hA, pv, cdf_tb);
+            float xB = mcx_draw(hB, pv, cdf_tb);
             mcx_accumulate_pair<MCX_ACC_S>(xA, xB, mcx_weight(xA, is_tb), mcx_weight(xB, is_tb), acc);
         }
         if (i < blk_end) {                                   // odd tail of the block
-            mcx_accumulate<MCX_ACC_S>(mcx_draw(mcx_pcg_out(st), a, cdf_tb), is_tb, acc);
+            mcx_accumulate<MCX_ACC_S>(mcx_draw(mcx_pcg_out(st), pv, cdf_tb), is_tb, acc);
             st += MCX_STATE_STEP;
             ++i;
         }
@@ -472,23 +599,12 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 #endif
 
 // One proposal of a non-normal family from one hash output.
-MCX_DEV float mcx_draw_proposal(u32 h, const McxMcmcArgs& a, const McxTable& cdf_tb) {
-#if MCX_DIST == MCX_DIST_UNIFORM
-    (void)cdf_tb;
-    return MCX_UNIT_PARAMS ? mcx_u01(h) : mcx_sample_uniform(mcx_u01(h), a.param1, a.param2);
-#elif MCX_DIST == MCX_DIST_EXPONENTIAL
-    (void)cdf_tb;
-    return mcx_sample_exponential(mcx_u01_closed(h), MCX_UNIT_PARAMS ? 1.0f : a.param1);
-#else
-    return mcx_sample_cdf(cdf_tb, mcx_u01_closed(h), h);
-#endif
-}
+MCX_DEV float mcx_draw_proposal(u32 h, const McxParamsV& pv, const McxTable& cdf_tb) { return mcx_draw(h, pv, cdf_tb); }
 
 extern "C" __global__ void __launch_bounds__(MCX_BLOCK)
 mcx_mcmc_kernel(McxMcmcArgs a) {
-#if !MCX_UNIT_PARAMS && MCX_DIST == MCX_DIST_NORMAL
-    const float mcx_affine_b = mcx_in_vgpr(a.param1);
-#endif
+    const McxParamsV pv = mcx_params_v(a);
+    (void)pv;
     u32 lds_off = 0u;
     McxTable cdf_tb = mcx_stage_table(a.cdf, lds_off);
     McxTable lp_tb = mcx_stage_table(a.target_logpdf, lds_off);
@@ -531,8 +647,8 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
         z_init = z0;
         ph_odd_draw = z1;          // normal: the deviate; mh_step_h applies the affine map
 #else
-        cur_x = mcx_draw_proposal(o.x, a, cdf_tb);
-        ph_odd_draw = mcx_draw_proposal(o.y, a, cdf_tb);
+        cur_x = mcx_draw_proposal(o.x, pv, cdf_tb);
+        ph_odd_draw = mcx_draw_proposal(o.y, pv, cdf_tb);
 #endif
         ph_odd_accept = o.w;
     }
@@ -548,11 +664,11 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     // proposal state for even `it`: counters 2*(it+OFFSET), 2*(it+OFFSET)+1
     u32 st_prop = mcx_state(a.seed, idx, 2u * (2u + MCX_PROP_ITER_OFFSET));
 #else
-    cur_x = mcx_draw_proposal(mcx_pcg_out(mcx_state(a.seed, idx, 0u)), a, cdf_tb);
+    cur_x = mcx_draw_proposal(mcx_pcg_out(mcx_state(a.seed, idx, 0u)), pv, cdf_tb);
     u32 st_prop = mcx_state(a.seed, idx, 1u + MCX_PROP_ITER_OFFSET);
 #endif
 #if MCX_WALK
-    cur_x += a.x0;                                            // chains start at x0 + d_0
+    cur_x += a.x0;                                            // chains start at x0 + d_0 (once per chain)
 #endif
     float cur_lp = MCX_LOGP(lp_tb, cur_x);
 #if MCX_WALK == 0
@@ -570,12 +686,13 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #endif
 
 #if MCX_WALK == 1 && MCX_Q_SAMPLER
-    const float rw_ms = MCX_UNIT_PARAMS ? 0.0f : a.param1 / a.param2;              // mean / std of the increments
+    const float rw_ms = MCX_UNIT_PARAMS ? 0.0f : mcx_in_vgpr(a.param1 / a.param2);  // mean / std of the increments
 #endif
     // Second half of a Metropolis-Hastings step (shader_gen.rs:527-537): accept test, state update, accumulation.
     // `it` is wave-uniform. prop_lq is used by the independent sampler only (it becomes the cached log q(current)).
 #if MCX_WALK == 3
     float ad_log_s = 0.0f, ad_scale = 1.0f;      // per-chain step scale, adapted during burn-in only
+    const float ad_target = mcx_in_vgpr(a.target_accept);
 #endif
     auto mh_finish = [&](u32 it, float prop_x, float prop_lp, float prop_lq, float log_alpha, u32 ha) {
 #if MCX_PRECISE_SAMPLER
@@ -606,7 +723,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
             // a chain that is still outside the target table rejects every proposal that does not land inside: that
             // says nothing about the scale, and shrinking it there would strand the chain
             const float g = was_inside ? __builtin_amdgcn_rsqf((float)it) : 0.0f;
-            ad_log_s = fmaf(g, (take ? 1.0f : 0.0f) - a.target_accept, ad_log_s);
+            ad_log_s = fmaf(g, (take ? 1.0f : 0.0f) - ad_target, ad_log_s);
             ad_scale = __builtin_amdgcn_exp2f(ad_log_s * 1.4426950408889634f);
         }
 #endif
@@ -676,8 +793,8 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
         mh_step_h(it, z0, o.z);
         if (it + 1u <= total_steps) mh_step_h(it + 1u, z1, o.w);      // wave-uniform
 #else
-        mh_step_h(it, mcx_draw_proposal(o.x, a, cdf_tb), o.z);
-        if (it + 1u <= total_steps) mh_step_h(it + 1u, mcx_draw_proposal(o.y, a, cdf_tb), o.w);
+        mh_step_h(it, mcx_draw_proposal(o.x, pv, cdf_tb), o.z);
+        if (it + 1u <= total_steps) mh_step_h(it + 1u, mcx_draw_proposal(o.y, pv, cdf_tb), o.w);
 #endif
     }
 #elif MCX_DIST == MCX_DIST_NORMAL
@@ -703,7 +820,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     for (u32 it = 1u; it <= total_steps; ++it) {
         u32 h = mcx_pcg_out(st_prop);
         st_prop += MCX_STATE_STEP;
-        mh_step(it, mcx_draw_proposal(h, a, cdf_tb));
+        mh_step(it, mcx_draw_proposal(h, pv, cdf_tb));
     }
 #endif
 #pragma unroll

@@ -28,6 +28,10 @@ void analyse_table(int kind, const float* keys, uint32_t n, float* inv_dk, std::
 // returns x[c] because the cell is narrower than 1e-10, distribution.rs:152-155), slope[n-1] = 0.
 void build_cdf_slopes(const float* cdf, const float* x, uint32_t n, std::vector<float>* slopes);
 
+// CDF tables: the bucket-direct inverse (see mcx_plan.cpp). direct = 2^bits records {x_b, slope * 2^-32} or
+// {lo | hi << 16, -0.0f}; empty when the table does not qualify.
+void build_cdf_direct(const float* cdf, const float* x, uint32_t n, std::vector<float>* direct, uint32_t* direct_bits);
+
 void cell_map(const float* keys, uint32_t n, float* scale, float* c0);
 void build_cells(const float* keys, const float* values, uint32_t n, std::vector<float>* cells);
 

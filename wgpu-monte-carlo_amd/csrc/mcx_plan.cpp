@@ -151,6 +151,63 @@ void analyse_table(int kind, const float* keys, uint32_t n, float* inv_dk, std::
     *guide_bits = bits;
 }
 
+// Bucket-direct inverse CDF. The inverse of a piecewise-linear CDF is piecewise linear in u with kinks at the table's
+// cdf values; cut [0, 1) into G = 2^bits equal buckets (bucket of a draw = the top `bits` bits of its hash word).
+// A bucket with NO cdf node inside lies in ONE cell c of the table -- the very cell the reference's lower-bound search
+// selects for every u of the bucket (distribution.rs:128-158) -- so there x(u) = x_b + s * (u - b/G) with
+// x_b = x[c] + s (b/G - cdf[c]), s = (x[c+1] - x[c]) / (cdf[c+1] - cdf[c]): the record {x_b, s * 2^-32} turns the
+// sample into one 8-byte read and one FMA on the low hash bits. A bucket WITH nodes stores its search window
+// {lo | hi << 16, -0.0f}: lo / hi = the lower bounds of b/G and (b+1)/G, between which the reference's search result
+// must lie; the sign bit of the second word is the flag (a non-negative slope never sets it). With G >= 4 n most of
+// the probability mass falls into node-free buckets (Beta(2,5), n = 2048, G = 8192: 83 %).
+// Not built (direct stays empty) for tables the guide is not valid for, or with a decreasing x column.
+void build_cdf_direct(const float* cdf, const float* x, uint32_t n, std::vector<float>* direct, uint32_t* direct_bits) {
+    direct->clear();
+    *direct_bits = 0u;
+    if (n < 2u || n > 4096u) return;                     // windows are packed in 16 bits; 12-step search exact for n <= 4096
+    for (uint32_t i = 1; i < n; ++i)
+        if (!(cdf[i] >= cdf[i - 1u]) || !(x[i] >= x[i - 1u])) return;
+    if (!(cdf[0] >= 0.0f) || !(cdf[n - 1u] <= 1.0f)) return;
+    uint32_t bits = 0u;
+    while ((1u << bits) < n) ++bits;
+    uint32_t extra = 2u;
+    if (const char* env = getenv("MCX_DIRECT_EXTRA_BITS")) extra = (uint32_t)atoi(env);      // tuning knob
+    bits += extra;
+    if (bits > 13u) bits = 13u;                          // 8192 records = 64 KiB of LDS
+    if (bits < 4u) bits = 4u;
+    const uint32_t G = 1u << bits;
+    std::vector<uint32_t> bound(G + 1u);
+    uint32_t i = 0u;
+    for (uint32_t b = 0; b <= G; ++b) {
+        const float q = (float)b / (float)G;
+        while (i < n - 1u && cdf[i] < q) ++i;            // first i in [0, n-2] with cdf[i] >= q, else n-1
+        bound[b] = i;
+    }
+    direct->resize(2ull * G);
+    for (uint32_t b = 0; b < G; ++b) {
+        const uint32_t lo = bound[b], hi = bound[b + 1u];
+        float w0, w1;
+        if (lo != hi) {                                  // nodes inside: search window, flagged by the sign of -0.0f
+            const uint32_t packed = lo | (hi << 16);
+            memcpy(&w0, &packed, 4);
+            w1 = -0.0f;
+        } else if (lo == 0u) {                           // the whole bucket is at or below cdf[0]: the lookup returns x[0]
+            w0 = x[0];
+            w1 = 0.0f;
+        } else {
+            const uint32_t c = lo - 1u;                  // cdf[c] < b/G and (b+1)/G <= cdf[c+1]
+            const double dc = (double)cdf[c + 1u] - (double)cdf[c];
+            const double s = dc > 0.0 ? ((double)x[c + 1u] - (double)x[c]) / dc : 0.0;
+            w0 = (float)((double)x[c] + s * ((double)b / (double)G - (double)cdf[c]));
+            w1 = (float)(s * 0x1.0p-32);
+            if (!(w1 >= 0.0f) || !std::isfinite(w0) || !std::isfinite(w1)) { direct->clear(); return; }
+        }
+        (*direct)[2ull * b] = w0;
+        (*direct)[2ull * b + 1u] = w1;
+    }
+    *direct_bits = bits;
+}
+
 void build_cdf_slopes(const float* cdf, const float* x, uint32_t n, std::vector<float>* slopes) {
     slopes->assign(n, 0.0f);
     for (uint32_t c = 0; c + 1u < n; ++c) {

@@ -271,6 +271,7 @@ class MonteCarloIntegrator:
         desc.tables_lds = 1
         if need > runtime.lds_table_budget(desc):
             desc.tables_lds = 0
+            desc.cdf_direct = 0            # the bucket-direct records only pay from LDS
         return desc
 
     def _run(self, rows: int, call):
@@ -320,6 +321,15 @@ class MonteCarloIntegrator:
         tables = [t for t in tables if t is not None]
         return bool(tables) and not self._precise_sampler and all(t.has_cells for t in tables)
 
+    def _cdf_direct(self, cdf: Optional[runtime.Table], k: int) -> bool:
+        """Sample a custom distribution through the bucket-direct form of its CDF table (one read + one FMA for draws
+        whose bucket holds no cdf node, the rest resolved in batches) when the table has one; math="precise" keeps the
+        reference's search + blend. Measured on Beta(2,5), 2e9 samples: 1.59 ms against 1.78 ms for the guided search at
+        K = 4, 2.22 / 2.35 ms at K = 16, 3.27 / 3.23 ms at K = 32 (the evaluation dominates there): used up to 16 rows."""
+        rows = k * (2 if self._std_error else 1)
+        return (cdf is not None and cdf.direct_bits > 0 and not self._precise_sampler and self._rng == runtime.RNG_PCG_REF
+                and rows <= 16 and not os.environ.get("MCX_NO_DIRECT"))
+
     def _rank_world(self):
         return (self._group.rank, self._group.world) if self._group is not None else (0, 1)
 
@@ -334,7 +344,7 @@ class MonteCarloIntegrator:
         desc = runtime.make_desc(runtime.KIND_INTEGRATE, k, code, guard_endpoints=self._guard,
                                  precise_sampler=self._precise_sampler, rng=self._rng,
                                  second_moments=self._std_error, unit_params=_unit_params(code, p1, p2),
-                                 moment_family=self._use_moment_family(functions))
+                                 moment_family=self._use_moment_family(functions), cdf_direct=self._cdf_direct(cdf, k))
         self._fit_tables(desc, cdf)
         return _Plan("integrate", self._engine.module(user_src, desc), desc, k, runtime.result_rows(desc), p1, p2,
                      dict(cdf=cdf))
@@ -369,7 +379,7 @@ class MonteCarloIntegrator:
                                  rng=self._rng, second_moments=self._std_error,
                                  unit_params=_unit_params(code, p1, p2),
                                  cell_tables=self._cell_tables(p_table, q_table), q_sampler=q_sampler,
-                                 moment_family=self._use_moment_family(functions))
+                                 moment_family=self._use_moment_family(functions), cdf_direct=self._cdf_direct(cdf, k))
         self._fit_tables(desc, cdf, p_table, q_table)
         return _Plan("integrate", self._engine.module(user_src, desc), desc, k, runtime.result_rows(desc), p1, p2,
                      dict(cdf=cdf, target_pdf=p_table, proposal_pdf=q_table))

@@ -47,7 +47,8 @@ class ModuleDesc(C.Structure):
                 ("precise_sampler", C.c_int32), ("block", C.c_int32), ("tables_lds", C.c_int32),
                 ("rng", C.c_int32), ("unit_params", C.c_int32), ("second_moments", C.c_int32),
                 ("walk", C.c_int32), ("cell_tables", C.c_int32), ("q_sampler", C.c_int32),
-                ("moment_family", C.c_int32), ("user_tables", C.c_int32), ("logpdf_analytic", C.c_int32)]
+                ("moment_family", C.c_int32), ("user_tables", C.c_int32), ("logpdf_analytic", C.c_int32),
+                ("cdf_direct", C.c_int32)]
 
 
 class IntegrateParams(C.Structure):
@@ -74,7 +75,7 @@ EXPORTED_SYMBOLS = [
     "mcx_mcmc", "mcx_mcmc_device", "mcx_integrate_multi", "mcx_mcmc_multi",
     "mcx_engine_last_launch_count", "mcx_module_static_lds", "mcx_lds_table_budget", "mcx_rccl_library",
     "mcx_comm_create", "mcx_comm_destroy", "mcx_comm_size", "mcx_integrate_comm", "mcx_mcmc_comm",
-    "mcx_selftest_streams", "mcx_set_max_launch_units",
+    "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct",
 ]
 
 _lib = None
@@ -159,6 +160,7 @@ def load():
         L.mcx_table_info.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(u32)]
         L.mcx_table_cell_map.argtypes = [C.POINTER(C.c_float), u32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mcx_table_has_cells.argtypes = [vp]
+        L.mcx_table_has_direct.argtypes = [vp]
         L.mcx_table_lds_bytes.argtypes = [vp]
         L.mcx_table_lds_bytes.restype = u32
         L.mcx_table_cells.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), u32, C.POINTER(C.c_float)]
@@ -242,12 +244,13 @@ def make_desc(kind: int, k: int, dist_type: int, weight: bool = False, p_table: 
               block: int = 0, tables_lds: bool = True, rng: int = 0, second_moments: bool = False,
               unit_params: bool = False, walk: int = 0, cell_tables: bool = False,
               q_sampler: bool = False, moment_family: bool = False, user_tables: int = 0,
-              logpdf_analytic: int = 0) -> ModuleDesc:
+              logpdf_analytic: int = 0, cdf_direct: bool = False) -> ModuleDesc:
     if not block and os.environ.get("MCX_BLOCK"):        # tuning knob
         block = int(os.environ["MCX_BLOCK"])
     return ModuleDesc(kind, k, dist_type, int(weight), int(p_table), int(q_table), int(guard_endpoints),
                       int(precise_sampler), int(block), int(tables_lds), int(rng), int(unit_params), int(second_moments),
-                      int(walk), int(cell_tables), int(q_sampler), int(moment_family), int(user_tables), int(logpdf_analytic))
+                      int(walk), int(cell_tables), int(q_sampler), int(moment_family), int(user_tables), int(logpdf_analytic),
+                      int(cdf_direct))
 
 
 def table_cells(keys, values):
@@ -337,6 +340,7 @@ class Table:
                                       len(keys), C.byref(self._h)))
         self.kind, self.n = kind, len(keys)
         self.has_cells = int(load().mcx_table_has_cells(self._h)) == 1     # slope-intercept cell form (strict grid)
+        self.direct_bits = int(load().mcx_table_has_direct(self._h))       # CDF tables: bucket-direct records (0: none)
         self.lds_bytes = int(load().mcx_table_lds_bytes(self._h))          # staged per workgroup when tables_lds = 1
 
     def info(self) -> dict:
