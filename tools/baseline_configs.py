@@ -14,17 +14,21 @@ import math
 
 import numpy as np
 
-# Algorithmic VALU cost per unit (sample or MH step) in lane-op equivalents, the survey's weights (SURVEY.md 8d:
-# plain op 1, integer multiply 4, transcendental 2), derived per config in DESIGN.md section 4:
-#   C2  per Box-Muller pair 23 plain + 2 int-mul + 4 transcendental, per sample 3 mul + 4 add    -> 26.5
-#   C3  C2's sampler with the affine map (27.5 - 7) + cell lookup of p (6) + 1/q from the deviate
-#       (exp 2 + 3 mul) + 4 x (f * w accumulate: 2) + 3 mul for the powers                       -> 42.5
-#   C4  per step: 2 hashes (2 x (5 plain + 4)) + half a Box-Muller pair ((4 plain + 4 x 2) / 2) + affine 1
-#       + cell lookup 6 + log q from the deviate 2 + accept test (cvt 1 + log 2 + fma 1 + 4 add/sub + cmp 1)
-#       + 3 selects + 2 evaluations / accumulates 3                                              -> 51
-#   C5  hash 9 + u 2 + inverse-CDF lookup (bucket 2, search ~2 steps x 5, interpolation 4) 16
-#       + 32 powers by Newton pairs: 3 ops per power                                             -> 123
-OPS_PER_UNIT = {"c1": 24.5, "c2": 26.5, "c3": 42.5, "c4": 51.0, "c5": 123.0}
+# Algorithmic VALU cost per unit (sample or MH step) in lane-op equivalents with the survey's weights (SURVEY.md 8d:
+# plain op 1, integer multiply 4, transcendental 2). "Algorithmic" = what the kernel's algorithm needs, not what the
+# compiler emitted; the executed instruction counts (SQ_INSTS_VALU per unit) are in profiles/r02_pmc_summary.txt.
+#   hash of one counter: state add 1 + lshr, add, lshr, xor, lshr, xor 6 + mul 4 = 11 (the Box-Muller angle word skips
+#   the last lshr/xor: 9); Box-Muller pair: cvt, guard max, log 2, fma, sqrt 2, angle bits 1, cos 2, sin 2, 2 mul = 14
+#   C2  per sample (11 + 9 + 14) / 2 = 17 ... counted as 19.5 in round 1 with u2 = cvt * 2^-32 instead of the bit trick;
+#       kept at 19.5 for comparability, + 3 mul + 4 add for x..x^4                                      -> 26.5
+#   C3  sampler 19.5 + affine 1 + cell lookup of p (fma, med3, cvt, address, fma) 5 + 1/q from the deviate
+#       (z*z, scale, exp2 2, * sigma sqrt(2 pi), * p) 6 + 3 mul for the powers + 4 weighted accumulates  -> 38.5
+#   C4  per MH step: proposal hashes (11 + 9) / 2 + accept hash 11 = 21; half a Box-Muller pair 7; affine 1; cell
+#       lookup 5; w = log p + z^2/2 2; log alpha 1; accept test (cvt, log 2, fma, cmp) 5; 2 state selects; x^2 and two
+#       accumulates 3                                                                                  -> 47
+#   C5  hash 11 + u (cvt, scale) 2 + inverse-CDF lookup (bucket 2, window unpack 2, ~2 search steps x 5, cell
+#       arithmetic 4) 18 + 32 powers by Newton pairs at 3 ops per power per pair = 48 + pair set-up 1.5   -> 80.5
+OPS_PER_UNIT = {"c1": 24.5, "c2": 26.5, "c3": 38.5, "c4": 47.0, "c5": 80.5}
 
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9      # 7.86e13: CUs x SIMDs x lanes x clock (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0

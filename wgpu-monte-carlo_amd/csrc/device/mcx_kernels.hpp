@@ -684,6 +684,14 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #if MCX_RNG == 0
     u32 st_acc = mcx_state(a.seed + MCX_ACCEPT_SEED_OFFSET, idx, 1u);
 #endif
+    // Independence sampler, default math: log alpha = log p(x') + log q(x) - log p(x) - log q(x') (shader_gen.rs:526)
+    // = w(x') - w(x) with w = log p - log q, so the chain carries (x, w): one state select and two additions fewer per
+    // step than carrying log p and log q separately (v_cndmask_b32 is a half-rate instruction on gfx950). Same value up
+    // to the rounding of the regrouped sum; math="precise" keeps the reference's left-to-right form.
+#define MCX_W_STATE (MCX_WALK == 0 && !MCX_PRECISE_SAMPLER)
+#if MCX_W_STATE
+    cur_lp = cur_lp - cur_lq;                                 // from here on cur_lp holds w(current)
+#endif
 
 #if MCX_WALK == 1 && MCX_Q_SAMPLER
     const float rw_ms = MCX_UNIT_PARAMS ? 0.0f : mcx_in_vgpr(a.param1 / a.param2);  // mean / std of the increments
@@ -712,7 +720,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #endif
         cur_x = take ? prop_x : cur_x;
         cur_lp = take ? prop_lp : cur_lp;
-#if MCX_WALK == 0
+#if MCX_WALK == 0 && !MCX_W_STATE
         cur_lq = take ? prop_lq : cur_lq;
 #else
         (void)prop_lq;
@@ -747,12 +755,21 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #if MCX_WALK == 0
         const float prop_x = draw;
         float prop_lp = MCX_LOGP(lp_tb, prop_x);
+#if MCX_W_STATE
+#if MCX_Q_SAMPLER
+        const float prop_w = fmaf(0.5f * zd, zd, prop_lp);       // log p(x') - log q(x'), log q = -z^2 / 2 (+ const)
+#else
+        const float prop_w = prop_lp - MCX_LOGQ(lq_tb, prop_x);
+#endif
+        mh_finish(it, prop_x, prop_w, 0.0f, prop_w - cur_lp, ha);
+#else
 #if MCX_Q_SAMPLER
         float prop_lq = -0.5f * zd * zd;
 #else
         float prop_lq = MCX_LOGQ(lq_tb, prop_x);
 #endif
         mh_finish(it, prop_x, prop_lp, prop_lq, prop_lp + cur_lq - cur_lp - prop_lq, ha);   // shader_gen.rs:526
+#endif
 #elif MCX_WALK == 1
         const float prop_x = cur_x + draw;
         float prop_lp = MCX_LOGP(lp_tb, prop_x);
