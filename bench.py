@@ -405,11 +405,12 @@ def run_rank(args):
     if rank == 0:
         value = units_per_step * args.steps / elapsed
         backend = "RCCL" if args.backend == "nccl" else args.backend
-        traffic = None
-        if args.config == "c2" and world == 1 and launch["n_blocks"] == 4096 and launch["launches"] == 1:
-            # separate rocprofv3 --pmc passes of this same command (profiles/r02_bench_n1_pmc_{fetch,write}.csv):
-            # WRITE_SIZE 128 KiB (= the algorithmic n_blocks * K * 8 B of partial sums) + FETCH_SIZE 37 KiB (code + arguments)
-            traffic = 128 * 1024 + 37.1 * 1024
+        # HBM traffic and executed instruction counts of this kernel come from separate rocprofv3 --pmc passes of this
+        # same command (tools/profile_all.sh -> profiles/r02_pmc_summary.txt); quoted only when that profile was taken
+        # with the launch geometry of this run, else null
+        traffic, pmc = None, pmc_summary(args.config, launch, world)
+        if pmc:
+            traffic = pmc.get("hbm_bytes_per_launch_corrected")
         line = {
             "metric": "samples/sec (whole node), K=4 fused functions on N(0,1)" if args.config == "c2" else
                       f"{wl.unit} (whole node), BASELINE config {args.config}",
@@ -456,6 +457,9 @@ def run_rank(args):
                                     f"on one stream, one HIP-event pair around all of them",
                 "per_rank_kernel_ms": per_rank_kernel_ms,
                 "ops_per_unit": ops,
+                "executed_valu_per_unit": pmc.get("valu_inst_per_unit") if pmc else None,
+                "valu_issue_frac_of_peak": pmc.get("valu_issue_frac_of_peak") if pmc else None,
+                "pmc_source": "profiles/r02_pmc_summary.txt (FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes; SQ_INSTS_VALU)" if pmc else None,
                 "units_per_launch": units_per_launch,
                 "launch": launch,
                 "note": "the binding resource of these fused kernels is vector-ALU issue (SURVEY.md 8d): ops_per_unit is "
@@ -481,6 +485,22 @@ def run_rank(args):
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
+
+
+def pmc_summary(config, launch, world):
+    """The committed PMC digest of this config's kernel (profiles/r02_pmc_summary.txt), if its launch geometry matches."""
+    path = ROOT / "profiles" / "r02_pmc_summary.txt"
+    if world != 1 or not path.exists():
+        return None
+    for text in path.read_text().splitlines():
+        try:
+            d = json.loads(text)
+        except ValueError:
+            continue
+        if d.get("config") == config and str(d.get("workgroup")) == str(launch["block"]) and \
+                str(d.get("grid")) == str(launch["n_blocks"] * launch["block"]) and launch["launches"] == 1:
+            return d
+    return None
 
 
 def prewarm_cache():
