@@ -206,3 +206,20 @@ def test_cell_index_map_keeps_both_table_ends_inside(lo, hi, n):
     outside = np.array([lo - 0.2 * dk - abs(lo) * 1e-6, hi + 0.2 * dk + abs(hi) * 1e-6, lo - 5 * dk, hi + 5 * dk], np.float32)
     got_out = np.clip(np.floor(fma(outside)), 0, n).astype(np.int64)
     assert list(got_out) == [0, n, 0, n]
+
+
+def test_default_device_follows_mcx_devices(monkeypatch):
+    """MCX_DEVICES maps LOCAL_RANK onto a list of device indices; no GPU needed to resolve it."""
+    from wgpu_montecarlo import api
+
+    monkeypatch.setenv("MCX_DEVICES", "4, 5,6,7")
+    monkeypatch.setenv("LOCAL_RANK", "2")
+    assert api._default_device() == 6
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert api._default_device() == 5                      # wraps: more ranks than listed devices share them
+    monkeypatch.setenv("MCX_DEVICES", "a,b")
+    with pytest.raises(ValueError, match="MCX_DEVICES"):
+        api._default_device()
+    monkeypatch.delenv("MCX_DEVICES")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    assert api._default_device() == 0

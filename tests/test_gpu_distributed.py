@@ -202,3 +202,30 @@ def test_one_thread_drives_several_engines(integrator):
     finally:
         for e in engines:
             e.close()
+
+
+def test_one_process_drives_several_devices_through_the_public_api(integrator):
+    """MonteCarloIntegrator(devices=[...]): one host thread, one engine per listed device, libmcx joins the shards
+    (RCCL communicator for distinct devices, host-side sum otherwise). The test box has one GPU, so the three
+    "devices" are three engines on GPU 0 (host-sum path; the RCCL path is exercised at runtime level in
+    test_gpu_runtime_limits.py and from plain C): every public entry point must reproduce the single-device values."""
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+
+    multi = MonteCarloIntegrator(devices=[0, 0, 0])
+    want = _calls(integrator, Distribution)
+    got = _calls(multi, Distribution)
+    for key, ref in want.items():
+        assert np.allclose(got[key], ref, rtol=1e-9, atol=1e-9), (key, got[key], ref)
+    res = multi.integrate([lambda x: x, lambda x: x**2], Distribution.normal(0.0, 1.0), n_samples=3_000_001, seed=5)
+    assert res.meta["devices"] == [0, 0, 0] and res.meta["collective"] == "host-sum"
+    assert res.meta["n_eff"] == integrator.integrate([lambda x: x], Distribution.normal(0.0, 1.0), n_samples=3_000_001).meta["n_eff"]
+    single = MonteCarloIntegrator(devices=[0])
+    assert single.integrate([lambda x: x], Distribution.normal(0.0, 1.0), n_samples=1000).meta["collective"] is None
+    with pytest.raises(ValueError, match="alternatives"):
+        MonteCarloIntegrator(devices=[0], process_group="world")
+    import torch
+
+    prepared = multi.prepare_integrate([lambda x: x], Distribution.normal(0.0, 1.0))
+    with pytest.raises(RuntimeError, match="devices"):
+        prepared.launch(1000, 1, torch.zeros(1, dtype=torch.float64, device="cuda"))
+    assert np.allclose(prepared.run(3_000_001, 5).values, want["normal"][:1], rtol=1e-9, atol=1e-9)

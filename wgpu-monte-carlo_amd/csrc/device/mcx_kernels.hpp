@@ -444,6 +444,9 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 #ifndef MCX_QCAP
 #define MCX_QCAP 128u                 // <= 63 left over + 64 appended
 #endif
+#ifndef MCX_DEFER_TEST
+#define MCX_DEFER_TEST 0
+#endif
     __attribute__((address_space(3))) u32* const queue =
         (__attribute__((address_space(3))) u32*)(mcx_lds_raw + lds_off) + (threadIdx.x >> 6) * MCX_QCAP;
     const u32 lane_id = threadIdx.x & 63u;
@@ -462,7 +465,10 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
     };
     // append the flagged lanes' hash words (m = their ballot); resolve a full batch as soon as there is one
     auto defer = [&](u64 m, bool flagged, u32 h) {
-        if (m != 0ull) {              // wave-uniform
+#if MCX_DEFER_TEST
+        if (m != 0ull)                // wave-uniform; almost always true (1 - 0.83^64), so by default not tested
+#endif
+        {
             const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, q_count));
             if (flagged) queue[pos] = h;
             q_count += (u32)__builtin_popcountll(m);

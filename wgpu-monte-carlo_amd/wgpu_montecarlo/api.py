@@ -192,17 +192,33 @@ def _unit_params(code: int, p1: float, p2: float) -> bool:
     return code == runtime.DIST_EXPONENTIAL and p1 == 1.0
 
 
+def _default_device() -> int:
+    """HIP device of an integrator built without `device=`: entry LOCAL_RANK of MCX_DEVICES (a comma-separated list
+    of device indices, e.g. "4,5,6,7" for a job that owns the upper half of a node) when that is set, else LOCAL_RANK
+    itself on a multi-GPU box, else 0."""
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    listed = [d for d in os.environ.get("MCX_DEVICES", "").replace(" ", "").split(",") if d]
+    if listed:
+        try:
+            return int(listed[local % len(listed)])
+        except ValueError:
+            raise ValueError(f"MCX_DEVICES must be a comma-separated list of device indices, got {os.environ['MCX_DEVICES']!r}")
+    return local if runtime.device_count() > 1 else 0
+
+
 class _Plan:
     """One compiled call: the module, its resident tables and the scalar parameters -- everything except the sizes and
     the seed, which are launch-time arguments. integrate* build a plan and launch it once; prepare_* hand it out."""
 
-    __slots__ = ("kind", "module", "desc", "k", "rows", "p1", "p2", "tables", "x0", "target_accept", "proposal_kind", "walk")
+    __slots__ = ("kind", "module", "desc", "k", "rows", "p1", "p2", "tables", "x0", "target_accept", "proposal_kind", "walk",
+                 "replicas")
 
     def __init__(self, kind, module, desc, k, rows, p1, p2, tables, x0=0.0, target_accept=0.44, proposal_kind="independent",
                  walk=0):
         self.kind, self.module, self.desc, self.k, self.rows = kind, module, desc, k, rows
         self.p1, self.p2, self.tables = p1, p2, tables
         self.x0, self.target_accept, self.proposal_kind, self.walk = x0, target_accept, proposal_kind, walk
+        self.replicas = None          # per-device copies of (engine, module, tables), MonteCarloIntegrator(devices=[...])
 
 
 class MonteCarloIntegrator:
@@ -211,7 +227,7 @@ class MonteCarloIntegrator:
     Args:
         target_threads: logical thread count T of the reference's sample grid (default 65536). It
             fixes the sample indexing (T, L = ceil(n/T)), not the physical launch geometry.
-        device: HIP device index (default: LOCAL_RANK if set, else 0).
+        device: HIP device index (default: entry LOCAL_RANK of MCX_DEVICES if that is set, else LOCAL_RANK, else 0).
         process_group: ranks to shard every call over. None (default): this GPU only, like the reference (set
             MCX_DISTRIBUTED=1 to make None mean "world"); "world": the world group of the initialised
             torch.distributed job; or a torch.distributed process group. Sharding is opt-in because every sharded
@@ -223,6 +239,11 @@ class MonteCarloIntegrator:
         rng: "pcg_ref" (default) is the reference's counter hash -- bit-exact sample indexing, but a 32-bit
             counter space that is oversubscribed beyond ~4e9 uniforms per call; "philox" is Philox4x32-10 with a
             128-bit counter (four iterations per call for integrate / importance sampling, one call per two MH steps).
+        devices: several HIP device indices driven by THIS process (no torch.distributed): every call is sharded over
+            them from one host thread and joined by libmcx's own RCCL communicator (include/mcx.h: mcx_comm_create --
+            one grouped ncclAllReduce of the K doubles over xGMI), or by a host-side sum when a device is listed more
+            than once or RCCL cannot be loaded. An alternative to one process per GPU; not combinable with
+            process_group.
         std_error: also accumulate sum (f_k w)^2 in the same pass; integrate / importance-sampling results then
             carry result.meta["std_error"][k] = sqrt((E[(f w)^2] - E[f w]^2) / N_eff) (extension; K <= 32).
             integrate_mcmc results carry batch-means standard errors over the independent chains plus
@@ -231,7 +252,7 @@ class MonteCarloIntegrator:
 
     def __init__(self, target_threads: Optional[int] = None, device: Optional[int] = None, process_group=None,
                  math: str = "default", strict_reference_uniform: bool = False, rng: str = "pcg_ref",
-                 std_error: bool = False):
+                 std_error: bool = False, devices: Optional[Sequence[int]] = None):
         runtime.load()                               # ImportError if libmcx.so has not been built
         if math not in ("default", "fast", "precise"):
             raise ValueError("math must be 'default', 'fast' or 'precise'")
@@ -239,11 +260,31 @@ class MonteCarloIntegrator:
             raise ValueError("rng must be 'pcg_ref' (the reference's stream) or 'philox'")
         self._rng = runtime.RNG_CODES[rng]
         self._std_error = bool(std_error)
+        if devices is not None:
+            devices = [int(d) for d in devices]
+            if not devices:
+                raise ValueError("devices must list at least one device index")
+            if process_group is not None:
+                raise ValueError("devices (one process driving several GPUs) and process_group (one process per GPU) are alternatives")
+            device = devices[0]
         if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0")) if runtime.device_count() > 1 else 0
+            device = _default_device()
         # RuntimeError("Failed to initialize GPU: ...") without a GPU. Engines are shared per device: building an
         # integrator per call (as the convenience functions do) costs no device initialisation after the first.
         self._engine = runtime.Engine.shared(device)
+        self._engines = [self._engine]
+        self._comm = None
+        if devices is not None and len(devices) > 1:
+            # a device listed twice gets engines of its own (RCCL then refuses: host-side sum)
+            seen, self._engines = set(), []
+            for d in devices:
+                self._engines.append(runtime.Engine.shared(d) if d not in seen else runtime.Engine(d))
+                seen.add(d)
+            if len(seen) == len(devices):
+                try:
+                    self._comm = runtime.Comm(self._engines)
+                except (RuntimeError, ValueError):
+                    self._comm = None
         self._integrator = self._engine             # attribute name the reference uses for its native object
         self._target_threads = target_threads
         self._math = math
@@ -274,12 +315,37 @@ class MonteCarloIntegrator:
             desc.cdf_direct = 0            # the bucket-direct records only pay from LDS
         return desc
 
-    def _run(self, rows: int, call):
+    def _replicas(self, plan: "_Plan"):
+        """[(engine, module, tables)] of a plan on every device of this integrator (built on first use)."""
+        if plan.replicas is None:
+            reps = [(self._engine, plan.module, plan.tables)]
+            for eng in self._engines[1:]:
+                tabs = {k: (eng.cached_table(t.kind, t.keys, t.values) if t is not None else None) for k, t in plan.tables.items()}
+                reps.append((eng, eng.module(plan.module.user_src, plan.desc), tabs))
+            plan.replicas = reps
+        return plan.replicas
+
+    def _run_devices(self, plan: "_Plan", sizes, seed: int):
+        """One host thread, several devices: device r runs shard r of len(devices); libmcx joins them."""
+        shards = self._replicas(plan)
+        if plan.kind == "mcmc":
+            n_steps, n_chains, n_burnin = sizes
+            fn = self._comm.mcmc if self._comm is not None else runtime.mcmc_multi
+            return fn(shards, n_steps, n_chains, n_burnin, seed, plan.p1, plan.p2, target_threads=self._target_threads,
+                      x0=plan.x0, target_accept=plan.target_accept)
+        fn = self._comm.integrate if self._comm is not None else runtime.integrate_multi
+        return fn(shards, sizes, seed, plan.p1, plan.p2, target_threads=self._target_threads)
+
+    def _run(self, rows: int, call, plan: "_Plan" = None, sizes=None, seed: int = 0):
         """Run one sharded launch and combine the ranks with ONE sum all-reduce of `rows` doubles.
 
         call(d_sums, stream) -> (host sums or None, n_eff). With an RCCL group the partial sums never
         leave the GPU before the collective: the kernels write them to a torch CUDA buffer on torch's
         current stream and the all-reduce runs on that buffer over xGMI."""
+        if len(self._engines) > 1 and plan is not None:
+            sums, n_eff = self._run_devices(plan, sizes, seed)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                return sums / float(n_eff), n_eff
         g = self._group
         if g is None or g.world < 2:
             sums, n_eff = call(None, None)
@@ -445,7 +511,8 @@ class MonteCarloIntegrator:
         plan = self._plan_integrate(functions, distribution)
         n_samples = _check_count(n_samples, "n_samples")
         seed = _check_seed(seed)
-        values, n_eff = self._run(plan.rows, lambda d_sums, stream: self._enqueue(plan, n_samples, seed, d_sums, stream))
+        values, n_eff = self._run(plan.rows, lambda d_sums, stream: self._enqueue(plan, n_samples, seed, d_sums, stream),
+                                  plan, n_samples, seed)
         self._warn_if_oversubscribed(n_eff)
         return IntegrationResult(values[:plan.k], n_samples, plan.k, self._meta(n_eff, values, plan.k))
 
@@ -457,7 +524,8 @@ class MonteCarloIntegrator:
         plan = self._plan_importance_sampling(functions, target_distribution, proposal_distribution)
         n_samples = _check_count(n_samples, "n_samples")
         seed = _check_seed(seed)
-        values, n_eff = self._run(plan.rows, lambda d_sums, stream: self._enqueue(plan, n_samples, seed, d_sums, stream))
+        values, n_eff = self._run(plan.rows, lambda d_sums, stream: self._enqueue(plan, n_samples, seed, d_sums, stream),
+                                  plan, n_samples, seed)
         return IntegrationResult(values[:plan.k], n_samples, plan.k, self._meta(n_eff, values, plan.k))
 
     # ---- K3 ----------------------------------------------------------------------------------------
@@ -488,7 +556,7 @@ class MonteCarloIntegrator:
         plan = self._plan_mcmc(functions, target_distribution, proposal_distribution, proposal_kind, initial_state,
                                target_accept)
         values, n_eff = self._run(plan.rows, lambda d_sums, stream: self._enqueue(
-            plan, (n_steps, n_chains, n_burnin), seed, d_sums, stream))
+            plan, (n_steps, n_chains, n_burnin), seed, d_sums, stream), plan, (n_steps, n_chains, n_burnin), seed)
         return self._mcmc_result(plan, values, n_eff, n_steps, n_chains, n_burnin)
 
     @staticmethod
@@ -552,7 +620,9 @@ class MonteCarloIntegrator:
         launch = self._engine.last_launch()
         rank, world = self._rank_world()
         meta = dict(n_eff=n_eff, kernel_ms=self._engine.last_kernel_ms(), n_blocks=launch["n_blocks"],
-                    block=launch["block"], lds_bytes=launch["lds_bytes"], rank=rank, world=world)
+                    block=launch["block"], lds_bytes=launch["lds_bytes"], rank=rank, world=world,
+                    devices=[e.device for e in self._engines],
+                    collective=("rccl" if self._comm is not None else "host-sum") if len(self._engines) > 1 else None)
         if values is not None and len(values) == 2 * k and k:
             with np.errstate(invalid="ignore", divide="ignore"):
                 var = np.maximum(values[k:] - values[:k] ** 2, 0.0)
@@ -572,6 +642,9 @@ class PreparedIntegrand:
         import torch
 
         owner = self._owner
+        if len(owner._engines) > 1:
+            raise RuntimeError("launch() enqueues on one device's stream; an integrator built with devices=[...] is "
+                               "driven through the blocking calls (integrate*, run)")
         if out.dtype != torch.float64 or out.numel() < self.rows or not out.is_contiguous():
             raise ValueError(f"out must be a contiguous float64 CUDA tensor with at least {self.rows} elements")
         stream = torch.cuda.current_stream(out.device).cuda_stream
@@ -594,7 +667,8 @@ class PreparedIntegrand:
     def run(self, n_samples: int, seed: int = 42) -> IntegrationResult:
         """Blocking form: same result as MonteCarloIntegrator.integrate() / integrate_importance_sampling()."""
         owner, plan = self._owner, self._plan
-        values, n_eff = owner._run(plan.rows, lambda d_sums, stream: owner._enqueue(plan, int(n_samples), seed, d_sums, stream))
+        values, n_eff = owner._run(plan.rows, lambda d_sums, stream: owner._enqueue(plan, int(n_samples), seed, d_sums, stream),
+                                   plan, int(n_samples), seed)
         return IntegrationResult(values[:plan.k], n_samples, plan.k, owner._meta(n_eff, values, plan.k))
 
 
@@ -612,7 +686,7 @@ class PreparedMcmc(PreparedIntegrand):
         """Blocking form: same result as MonteCarloIntegrator.integrate_mcmc()."""
         owner, plan = self._owner, self._plan
         sizes = MonteCarloIntegrator._check_mcmc_sizes(n_steps, n_chains, n_burnin)
-        values, n_eff = owner._run(plan.rows, lambda d_sums, stream: owner._enqueue(plan, sizes, seed, d_sums, stream))
+        values, n_eff = owner._run(plan.rows, lambda d_sums, stream: owner._enqueue(plan, sizes, seed, d_sums, stream), plan, sizes, seed)
         return owner._mcmc_result(plan, values, n_eff, *sizes)
 
 

@@ -339,6 +339,7 @@ class Table:
         check(load().mcx_table_create(engine._h, kind, keys.ctypes.data_as(fp), values.ctypes.data_as(fp),
                                       len(keys), C.byref(self._h)))
         self.kind, self.n = kind, len(keys)
+        self.keys, self.values = keys, values                              # kept: the table is re-created per device
         self.has_cells = int(load().mcx_table_has_cells(self._h)) == 1     # slope-intercept cell form (strict grid)
         self.direct_bits = int(load().mcx_table_has_direct(self._h))       # CDF tables: bucket-direct records (0: none)
         self.lds_bytes = int(load().mcx_table_lds_bytes(self._h))          # staged per workgroup when tables_lds = 1
@@ -364,6 +365,7 @@ class Module:
     def __init__(self, engine: "Engine", user_src: str, desc: ModuleDesc):
         self._engine = engine
         self.desc = desc
+        self.user_src = user_src
         self._h = C.c_void_p()
         check(load().mcx_module_build(engine._h, user_src.encode(), C.byref(desc), C.byref(self._h)))
         self.static_lds = int(load().mcx_module_static_lds(self._h))
