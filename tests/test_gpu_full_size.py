@@ -147,6 +147,34 @@ def test_c5_oracle_parity_at_1e8(math, tol):
     assert np.all(err <= tol * np.abs(want) + tol * 1e-2), (math, err / np.abs(want))
 
 
+@pytest.mark.parametrize("case", ["beta-4", "beta-16", "laplace-4"])
+def test_bucket_direct_sampler_oracle_parity_at_1e8(case):
+    """The bucket-direct + queue form of the CDF sampler (K <= 16 rows, reference stream) at 1e8 samples against the
+    oracle's capped search + blend on the same stream: same cell for every draw, the cell's line evaluated on the
+    unrounded low hash bits. Laplace on (-12, 12): both tails flat, x of both signs. Bound: 2e-5 of
+    the magnitude E|x|^k of the summed terms (1 for Beta on [0, 1], k! for the unit Laplace)."""
+    import math
+
+    from wgpu_montecarlo import Distribution
+
+    name, k = case.split("-")
+    k = int(k)
+    if name == "beta":
+        dist, scale = Distribution.beta(2.0, 5.0), np.ones(k)
+    else:
+        dist = Distribution.from_pdf(lambda x: math.exp(-abs(x)) / 2, support=(-12.0, 12.0))
+        scale = np.array([math.factorial(j) for j in range(1, k + 1)], dtype=np.float64)
+    fns = bc.moment_functions(k) if k == 4 else [lambda x, j=j: x**j for j in range(1, k + 1)]
+    res = _mc().integrate(fns, dist, n_samples=10**8, seed=7)
+    assert res.meta["lds_bytes"] == 8 * 8192 + 16 * 128 * 4              # records + queues: the direct form ran
+    ref = oracle.integrate(ORC_POW(k), oracle.CUSTOM, 0.0, 0.0, n_samples=10**8, seed=7, guard=1,
+                           cdf_table=dist._cdf_table, x_table=dist._x_table)
+    assert res.meta["n_eff"] == ref["n_eff"]
+    want = ref["sums"] / ref["n_eff"]
+    err = np.abs(res.values - want)
+    assert np.all(err <= 2e-5 * scale), (case, err / scale)
+
+
 @pytest.mark.parametrize("math,tol", [("default", 2e-4), ("precise", 2e-4)])
 def test_c4_oracle_parity_at_65536_chains(math, tol):
     """C4's real step counts (1000 + 10 000) on 65 536 chains = 7.2e8 MH steps against the oracle's table semantics.
