@@ -195,6 +195,13 @@ def cpu_baseline(config: str, target_seconds: float):
                       f"stream) with OpenMP on {oracle.num_threads()} threads, {dt:.1f} s wall")
     if truth is not None:
         out["mean_error_vs_truth"] = [float(v) for v in (res["sums"][:len(truth)] / res["n_eff"] - truth)]
+    try:                                          # name the host CPU next to the core count
+        with open("/proc/cpuinfo") as fh:
+            models = [line.split(":", 1)[1].strip() for line in fh if line.startswith("model name")]
+        out["cpu_model"] = models[0] if models else None
+        out["logical_cpus"] = os.cpu_count()
+    except OSError:
+        pass
     return out
 
 
