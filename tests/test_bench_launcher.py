@@ -64,8 +64,13 @@ def test_a_failing_rank_takes_the_job_down_quickly():
 
 def test_driver_style_launch_is_still_accepted():
     """Under `python -m torch.distributed.run` WORLD_SIZE is already set: bench.py is then one of the ranks."""
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29671", str(ROOT / "bench.py"), "--gpus", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2",
                           "--rehearse-cpu"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
