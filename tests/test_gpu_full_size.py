@@ -11,6 +11,7 @@ Full size: N_eff / padded chains bit-exact (the reference's indexing contract), 
 closed-form truth for BOTH streams at the sizes the 32-bit counter space covers, and with the Philox stream beyond it
 (C4 draws 2.3e10 uniforms, C5 1e10: the reference stream is oversubscribed there and only marginally inside 3 sigma --
 measured over 24 seeds in profiles/r01_seed_sweep_c2_c5.jsonl -- so for it the assertion is a looser 5 sigma)."""
+import math
 import sys
 from pathlib import Path
 
@@ -153,8 +154,6 @@ def test_bucket_direct_sampler_oracle_parity_at_1e8(case):
     oracle's capped search + blend on the same stream: same cell for every draw, the cell's line evaluated on the
     unrounded low hash bits. Laplace on (-12, 12): both tails flat, x of both signs. Bound: 2e-5 of
     the magnitude E|x|^k of the summed terms (1 for Beta on [0, 1], k! for the unit Laplace)."""
-    import math
-
     from wgpu_montecarlo import Distribution
 
     name, k = case.split("-")
@@ -173,6 +172,39 @@ def test_bucket_direct_sampler_oracle_parity_at_1e8(case):
     want = ref["sums"] / ref["n_eff"]
     err = np.abs(res.values - want)
     assert np.all(err <= 2e-5 * scale), (case, err / scale)
+
+
+def test_bucket_direct_sampler_equals_the_guided_search(monkeypatch):
+    """Same draws, same cells: the bucket-direct + queue form against the guided search (MCX_NO_DIRECT=1) on the same
+    stream, for plain moments, second moments (std_error: 2K rows), a general (non-polynomial) integrand whose value
+    at the flagged lanes' placeholder x would be wrong if it leaked into a sum, and importance sampling with a custom
+    proposal. Agreement to float rounding of the per-sample interpolation (2.4e-7 * slope), far below 3 sigma."""
+    from wgpu_montecarlo import Distribution
+
+    beta = Distribution.beta(2.0, 5.0)
+    lap = Distribution.from_pdf(lambda x: math.exp(-abs(x)) / 2, support=(-12.0, 12.0))
+
+    def calls(mc_plain, mc_se):
+        out = {}
+        out["moments"] = mc_plain.integrate(bc.moment_functions(4), beta, n_samples=20_000_001, seed=3)
+        out["second"] = mc_se.integrate(bc.moment_functions(4), beta, n_samples=20_000_001, seed=3)
+        out["general"] = mc_plain.integrate([lambda x: 1.0 / (x + 0.25), lambda x: math.cos(3.0 * x) + 2.0, lambda x: x > 0.5],
+                                            beta, n_samples=20_000_001, seed=4)
+        out["is"] = mc_plain.integrate_importance_sampling([lambda x: x, lambda x: x * x], Distribution.normal(0.0, 1.0), lap,
+                                                           n_samples=20_000_001, seed=5)
+        return out
+
+    direct = calls(_mc(), _mc(std_error=True))
+    assert direct["moments"].meta["lds_bytes"] == 8 * 8192 + 16 * 128 * 4
+    monkeypatch.setenv("MCX_NO_DIRECT", "1")
+    guided = calls(_mc(), _mc(std_error=True))
+    assert guided["moments"].meta["lds_bytes"] != direct["moments"].meta["lds_bytes"]
+    for key in direct:
+        a, b = direct[key], guided[key]
+        assert a.meta["n_eff"] == b.meta["n_eff"]
+        assert np.allclose(a.values, b.values, rtol=3e-6, atol=3e-6), (key, a.values, b.values)
+    assert np.allclose(direct["second"].meta["std_error"], guided["second"].meta["std_error"], rtol=1e-4)
+    assert abs(direct["general"].values[2] - 0.109375) < 1e-3          # P(Beta(2,5) > 0.5) = 7/64
 
 
 @pytest.mark.parametrize("math,tol", [("default", 2e-4), ("precise", 2e-4)])
