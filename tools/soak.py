@@ -46,7 +46,7 @@ def main():
     calls = 0
     first = None
     while time.time() - t0 < args.seconds:
-        kind = int(rng.integers(0, 6))
+        kind = int(rng.integers(0, 9))
         mc = MonteCarloIntegrator(target_threads=int(rng.choice([256, 4096, 65536])), rng=str(rng.choice(["pcg_ref", "philox"])),
                                   std_error=bool(rng.integers(0, 2)))
         fns = make_fn(float(rng.integers(1, 40)) / 8.0)[: int(rng.integers(1, 5))]
@@ -65,10 +65,38 @@ def main():
         elif kind == 4:
             r = mc.integrate_mcmc(fns, Distribution.normal(0.5, 1.0), Distribution.normal(0.0, 2.0), n_steps=int(rng.choice([10, 200])),
                                   n_chains=int(rng.choice([100, 4096])), n_burnin=int(rng.choice([0, 20])), seed=calls)
-        else:
+        elif kind == 5:
             r = mc.integrate_mcmc(fns, Distribution.normal(0.5, 1.0), Distribution.uniform(-1.0, 1.0), n_steps=int(rng.choice([10, 200])),
                                   n_chains=int(rng.choice([100, 4096])), n_burnin=int(rng.choice([0, 20])), seed=calls,
                                   proposal_kind="random_walk")
+        elif kind == 6:
+            # the bucket-direct sampler against the guided search on a random table: same draws, same cells
+            dist = Distribution.beta(1.2 + 2 * float(rng.random()), 1.5 + 3 * float(rng.random()), table_size=int(rng.choice([300, 1000, 2048, 4000])))
+            mc = MonteCarloIntegrator(target_threads=int(rng.choice([256, 65536])), std_error=bool(rng.integers(0, 2)))
+            r = mc.integrate(fns, dist, n_samples=n, seed=calls)
+            os.environ["MCX_NO_DIRECT"] = "1"
+            try:
+                g = MonteCarloIntegrator(target_threads=mc._target_threads, std_error=mc._std_error).integrate(fns, dist, n_samples=n, seed=calls)
+            finally:
+                del os.environ["MCX_NO_DIRECT"]
+            assert np.allclose(r.values, g.values, rtol=5e-6, atol=5e-6), (r.values, g.values)
+        elif kind == 7:
+            # one process, three engines on this GPU (host-sum path of MonteCarloIntegrator(devices=[...])), split launches
+            from wgpu_montecarlo import runtime as rt
+
+            multi = MonteCarloIntegrator(devices=[0, 0, 0], rng=str(rng.choice(["pcg_ref", "philox"])))
+            rt.set_max_launch_units(int(rng.choice([0, 1_000_000, 7_000_000])))
+            try:
+                r = multi.integrate(fns, Distribution.normal(0.0, 1.0), n_samples=n, seed=calls)
+                one = MonteCarloIntegrator(rng="pcg_ref" if multi._rng == 0 else "philox").integrate(fns, Distribution.normal(0.0, 1.0), n_samples=n, seed=calls)
+            finally:
+                rt.set_max_launch_units(0)
+            assert np.allclose(r.values, one.values, rtol=1e-8, atol=1e-8), (r.values, one.values)
+            for eng in multi._engines[1:]:
+                eng.close()
+        else:
+            lap = Distribution.from_pdf(lambda x: math.exp(-abs(x)) / 2, support=(-12.0, 12.0), table_size=int(rng.choice([512, 2048])))
+            r = mc.integrate_importance_sampling(fns, Distribution.normal(0.0, 1.0), lap, n_samples=n, seed=calls)
         assert np.all(np.isfinite(r.values)), (kind, r.values)
         calls += 1
         if calls % 100 == 0:
