@@ -81,6 +81,11 @@ int mcx_shard_integrate(const mcx_dispatch* d, int dist_type, uint32_t rank, uin
  * Box-Muller pair), 4 (Philox stream: one call). */
 int mcx_shard_units(const mcx_dispatch* d, uint32_t iterations_per_unit, uint32_t rank, uint32_t world, mcx_shard* out);
 
+/* Recommended mcx_module_desc.block for an MCMC module whose launches carry `chains` chains on one GPU (a rank's share
+ * of a chain-sharded run): the largest of 1024 / 512 / 256 threads that still gives every CU >= 4 workgroups, else 256.
+ * One chain per thread: with 1024-thread workgroups a 131 072-chain shard would occupy half the CUs. */
+uint32_t mcx_mcmc_block_hint(uint32_t chains);
+
 /* One rank's contiguous share of the padded chain range [0, T), in multiples of 256 chains. */
 int mcx_shard_chains(uint32_t total_chains, uint32_t rank, uint32_t world,
                      uint32_t* chain_begin, uint32_t* chain_count);

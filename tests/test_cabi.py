@@ -223,3 +223,10 @@ def test_default_device_follows_mcx_devices(monkeypatch):
     monkeypatch.delenv("MCX_DEVICES")
     monkeypatch.setenv("LOCAL_RANK", "0")
     assert api._default_device() == 0
+
+
+def test_mcmc_block_hint_keeps_every_cu_busy():
+    """One chain per thread: the workgroup size of an MCMC launch follows the chain count of the rank's shard (C4 over
+    1 / 2 / 4 / 8 GPUs: 1 048 576 / 524 288 / 262 144 / 131 072 chains) so that 256 CUs get >= 4 workgroups each."""
+    assert [rt.mcmc_block_hint(c) for c in (1_048_576, 524_288, 262_144, 131_072, 65_536, 256, 0)] == [1024, 512, 256, 256, 256, 256, 256]
+    assert rt.mcmc_block_hint(2**31) == 1024

@@ -84,6 +84,20 @@ int mcx_shard_chains(uint32_t total_chains, uint32_t rank, uint32_t world,
     return MCX_OK;
 }
 
+// Workgroup size for an MCMC launch of `chains` chains on one GPU (one chain per thread, so the chain count IS the
+// parallelism). 1024-thread workgroups share one LDS copy of the tables between 16 waves and are best when every CU
+// gets several of them; a rank's share of a chain-sharded run (BASELINE C4 over 8 GPUs: 131 072 chains) would leave
+// half of the 256 CUs without any workgroup at that size. Measured on C4's kernel (profiles/
+// r02_mcmc_block_size_vs_chain_count.txt, ms at 256 / 512 / 1024 threads): 1 048 576 chains 9.40 / 9.33 / 9.29;
+// 524 288: 5.27 / 5.23 / 5.31; 262 144: 2.93 / 2.95 / 2.90; 131 072: 1.84 / 1.88 / 2.78; 65 536: 1.42 / 1.78 / 2.71.
+// Rule: the largest size that still yields >= 4 workgroups per CU, else 256.
+uint32_t mcx_mcmc_block_hint(uint32_t chains) {
+    for (uint32_t block : {1024u, 512u}) {
+        if ((uint64_t)chains / block >= 4ull * 256ull) return block;
+    }
+    return 256u;
+}
+
 }  // extern "C"
 
 namespace mcx {

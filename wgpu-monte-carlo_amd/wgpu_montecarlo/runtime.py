@@ -75,7 +75,7 @@ EXPORTED_SYMBOLS = [
     "mcx_mcmc", "mcx_mcmc_device", "mcx_integrate_multi", "mcx_mcmc_multi",
     "mcx_engine_last_launch_count", "mcx_module_static_lds", "mcx_lds_table_budget", "mcx_rccl_library",
     "mcx_comm_create", "mcx_comm_destroy", "mcx_comm_size", "mcx_integrate_comm", "mcx_mcmc_comm",
-    "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct",
+    "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct", "mcx_mcmc_block_hint",
 ]
 
 _lib = None
@@ -161,6 +161,8 @@ def load():
         L.mcx_table_cell_map.argtypes = [C.POINTER(C.c_float), u32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mcx_table_has_cells.argtypes = [vp]
         L.mcx_table_has_direct.argtypes = [vp]
+        L.mcx_mcmc_block_hint.argtypes = [u32]
+        L.mcx_mcmc_block_hint.restype = u32
         L.mcx_table_lds_bytes.argtypes = [vp]
         L.mcx_table_lds_bytes.restype = u32
         L.mcx_table_cells.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), u32, C.POINTER(C.c_float)]
@@ -231,6 +233,11 @@ def shard_units(d: Dispatch, iterations_per_unit: int, rank: int, world: int) ->
     s = Shard()
     check(load().mcx_shard_units(C.byref(d), int(iterations_per_unit), int(rank), int(world), C.byref(s)))
     return s
+
+
+def mcmc_block_hint(chains: int) -> int:
+    """Workgroup size for an MCMC launch of `chains` chains on one GPU (include/mcx.h: mcx_mcmc_block_hint)."""
+    return int(load().mcx_mcmc_block_hint(int(chains)))
 
 
 def shard_chains(total_chains: int, rank: int, world: int):
