@@ -28,12 +28,14 @@ def test_lds_budget_accounts_for_static_scratch(integrator):
         pdf = lambda x: np.exp(-0.5 * x * x)
         proposal = Distribution.normal(0.0, 1.5)                  # log q from the sampler's deviate: only the target table is staged
         fits = Distribution.from_pdf(pdf, support=(-8.0, 8.0), table_size=budget // 8 - 64)
-        res = mc.integrate_mcmc(fns, fits, proposal, n_steps=60, n_chains=1024, n_burnin=10, seed=3)
+        # 1 048 576 chains: the launch uses 1024-thread workgroups (mcx_mcmc_block_hint), whose 16 waves need the 6.1 KiB
+        chains = 1_048_576
+        res = mc.integrate_mcmc(fns, fits, proposal, n_steps=12, n_chains=chains, n_burnin=3, seed=3)
         assert np.all(np.isfinite(res.values))
         assert budget - 1024 < res.meta["lds_bytes"] <= budget    # staged, right up to the budget
         # a table inside the old 156 KiB limit but beyond what the static scratch leaves: must fall back, not fail
         big = Distribution.from_pdf(pdf, support=(-8.0, 8.0), table_size=(155 * 1024) // 8)
-        res_big = mc.integrate_mcmc(fns, big, proposal, n_steps=60, n_chains=1024, n_burnin=10, seed=3)
+        res_big = mc.integrate_mcmc(fns, big, proposal, n_steps=12, n_chains=chains, n_burnin=3, seed=3)
         assert np.all(np.isfinite(res_big.values)) and res_big.meta["lds_bytes"] == 0
         assert np.allclose(res_big.values[:2], res.values[:2], atol=0.05)        # same chains, finer table of the same density
         # the C-level contract: forcing the staged build for that table is refused with a clear message
@@ -45,7 +47,10 @@ def test_lds_budget_accounts_for_static_scratch(integrator):
         forced = rt.make_desc(rt.KIND_MCMC, 16, rt.DIST_NORMAL, second_moments=True, cell_tables=tb.has_cells, q_sampler=True)
         mod = mc._engine.module(functions_to_hip(fns), forced)
         with pytest.raises(ValueError, match="do not fit in LDS"):
-            mc._engine.mcmc(mod, 60, 1024, 10, 3, 0.0, 1.5, tb, None)
+            mc._engine.mcmc(mod, 12, chains, 3, 3, 0.0, 1.5, tb, None)
+        # a small call picks 256-thread workgroups: 4 waves of scratch instead of 16, and the same table is staged
+        small = mc.integrate_mcmc(fns, big, proposal, n_steps=60, n_chains=1024, n_burnin=10, seed=3)
+        assert small.meta["block"] == 256 and small.meta["lds_bytes"] == tb.lds_bytes
     finally:
         mc._engine.close()
 
@@ -184,3 +189,17 @@ def test_module_eviction_waits_for_launches_in_flight():
     finally:
         rt.Engine.MAX_MODULES = old_max
         eng.close()
+
+
+@pytest.mark.parametrize("mode", ["plain", "torch_first", "torch_after_cuda", "torch_after_noclose"])
+def test_process_exits_cleanly_whatever_the_import_order(mode):
+    """RCCL is bound at run time; PyTorch ships its own copy. Creating a communicator and importing torch afterwards
+    used to end in `double free or corruption` at interpreter exit, and a communicator left open segfaulted during
+    teardown (tools/exit_order_probe.py). Each mode runs in its own process and must exit with code 0."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    probe = Path(__file__).resolve().parent.parent / "tools" / "exit_order_probe.py"
+    res = subprocess.run([sys.executable, str(probe), mode], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and f"done {mode}" in res.stdout, (res.returncode, res.stdout[-500:], res.stderr[-1500:])

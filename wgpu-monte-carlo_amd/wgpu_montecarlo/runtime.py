@@ -533,6 +533,9 @@ class Engine:
         return sums, int(n_eff.value)
 
     def close(self) -> None:
+        for comm in list(globals().get("_live_comms", ())):      # a communicator over this engine goes first
+            if any(e is self for e in comm._engines):
+                comm.close()
         for mod in list(self._modules.values()):
             mod.release()
         self._modules.clear()
@@ -587,11 +590,24 @@ class Comm:
     mcx_comm_create). shards as for integrate_multi: [(Engine, Module, tables-dict)], one per distinct device."""
 
     def __init__(self, engines):
+        # When PyTorch is installed, the RCCL that matches the HIP runtime of this process is PyTorch's bundled copy
+        # (_share_torch_hip_runtime). It must be brought in by PyTorch's own loader: dlopen-ing it first and importing
+        # torch afterwards ends in a double free at interpreter exit (measured on the GPU box: communicator created,
+        # then `import torch` -> abort at exit; torch first -> clean). So a process that uses the communicator imports
+        # torch here, before libmcx binds RCCL. Without PyTorch the system RCCL and HIP runtime are used.
+        import sys
+
+        if "torch" not in sys.modules and os.environ.get("MCX_RCCL", "").endswith("/torch/lib/librccl.so"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         self._engines = list(engines)
         n = len(self._engines)
         self._h = C.c_void_p()
         arr = (C.c_void_p * n)(*[e._h for e in self._engines])
         check(load().mcx_comm_create(arr, n, C.byref(self._h)))
+        _live_comms.add(self)          # destroyed at exit before the engines and before the runtimes unload
 
     @property
     def size(self) -> int:
@@ -640,4 +656,20 @@ def rccl_library() -> str:
     return (load().mcx_rccl_library() or b"").decode()
 
 
+import weakref  # noqa: E402
+
+_live_comms = weakref.WeakSet()
+
+
+def _close_comms() -> None:
+    """Communicators still alive at interpreter exit are destroyed here, while RCCL and the HIP runtime are fully
+    alive (a communicator left to __del__ during module teardown segfaulted on the GPU box)."""
+    for comm in list(_live_comms):
+        try:
+            comm.close()
+        except Exception:
+            pass
+
+
 atexit.register(Engine.close_shared)
+atexit.register(_close_comms)           # atexit runs last-registered first: communicators go before their engines
