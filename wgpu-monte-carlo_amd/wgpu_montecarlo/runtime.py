@@ -334,6 +334,12 @@ def hip_runtime() -> str:
 
 
 # ---- handles ---------------------------------------------------------------------------------------
+import weakref  # noqa: E402
+
+_live_engines = weakref.WeakSet()
+_live_comms = weakref.WeakSet()
+
+
 class Table:
     def __init__(self, engine: "Engine", kind: int, keys: np.ndarray, values: np.ndarray):
         keys = np.ascontiguousarray(keys, dtype=np.float32)
@@ -401,6 +407,7 @@ class Engine:
         self.device = int(device)
         self._modules = {}
         self._tables = {}
+        _live_engines.add(self)        # closed at interpreter exit while the HIP runtime is still fully alive
 
     @classmethod
     def shared(cls, device: int = 0) -> "Engine":
@@ -533,7 +540,7 @@ class Engine:
         return sums, int(n_eff.value)
 
     def close(self) -> None:
-        for comm in list(globals().get("_live_comms", ())):      # a communicator over this engine goes first
+        for comm in list(_live_comms):      # a communicator over this engine goes first
             if any(e is self for e in comm._engines):
                 comm.close()
         for mod in list(self._modules.values()):
@@ -656,17 +663,17 @@ def rccl_library() -> str:
     return (load().mcx_rccl_library() or b"").decode()
 
 
-import weakref  # noqa: E402
-
-_live_comms = weakref.WeakSet()
-
-
 def _close_comms() -> None:
     """Communicators still alive at interpreter exit are destroyed here, while RCCL and the HIP runtime are fully
     alive (a communicator left to __del__ during module teardown segfaulted on the GPU box)."""
     for comm in list(_live_comms):
         try:
             comm.close()
+        except Exception:
+            pass
+    for eng in list(_live_engines):        # engines that are not in Engine._shared (built directly or per duplicate device)
+        try:
+            eng.close()
         except Exception:
             pass
 
