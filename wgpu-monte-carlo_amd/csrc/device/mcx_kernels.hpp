@@ -806,6 +806,30 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     };
 #endif
 
+    // For the independence sampler everything about a proposal except the compare and the selects is independent of
+    // the chain's state, so both proposals of a trip (points, table reads, w) are produced before the first accept
+    // test: two LDS reads in flight instead of one read per uniform branch of mh_finish. Measured on C4's kernel (ms
+    // without / with): 1 048 576 chains 9.43 / 9.40, 524 288: 5.33 / 5.18, 131 072: 1.85 / 1.78, 65 536: 1.43 / 1.33 --
+    // it pays most where a small shard leaves 2-4 waves per SIMD and the step's dependent chain is exposed. (Round 1
+    // measured the same re-ordering slower, 13.76 against 13.4 ms: that was with flat_load lookups.) Not for the Philox
+    // stream: there the trip already carries a 20-multiply Philox call and the batched form measured 12.8 against
+    // 11.9 ms on C4.
+#ifndef MCX_MH_BATCH
+#define MCX_MH_BATCH (MCX_W_STATE && MCX_DIST == MCX_DIST_NORMAL && MCX_RNG == 0)
+#endif
+#if MCX_MH_BATCH
+    auto mh_two_steps = [&](u32 it, float z0, float z1, u32 ha0, u32 ha1) {
+        const float x0 = MCX_AFFINE(z0), x1 = MCX_AFFINE(z1);
+        const float lp0 = MCX_LOGP(lp_tb, x0), lp1 = MCX_LOGP(lp_tb, x1);
+#if MCX_Q_SAMPLER
+        const float w0 = fmaf(0.5f * z0, z0, lp0), w1 = fmaf(0.5f * z1, z1, lp1);
+#else
+        const float w0 = lp0 - MCX_LOGQ(lq_tb, x0), w1 = lp1 - MCX_LOGQ(lq_tb, x1);
+#endif
+        mh_finish(it, x0, w0, 0.0f, w0 - cur_lp, ha0);
+        mh_finish(it + 1u, x1, w1, 0.0f, w1 - cur_lp, ha1);
+    };
+#endif
 #if MCX_RNG == 1
     if (total_steps >= 1u) mh_step_h(1u, ph_odd_draw, ph_odd_accept);
     for (u32 it = 2u; it <= total_steps; it += 2u) {
@@ -825,15 +849,6 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     // new pair from counters 2*(it+OFFSET), +1 (distribution.rs:90-114 through shader_gen.rs:481)
     u32 it = 1u;
     if (total_steps >= 1u) { mh_step(1u, z_cached); it = 2u; }
-    // For the independence sampler everything about a proposal except the compare and the selects is independent of
-    // the chain's state, so both proposals of a trip (points, table reads, w, accept hashes) are produced before the
-    // first accept test: two LDS reads in flight instead of one read per uniform branch of mh_finish. Measured on C4's
-    // kernel (ms without / with): 1 048 576 chains 9.43 / 9.40, 524 288: 5.33 / 5.18, 131 072: 1.85 / 1.78, 65 536:
-    // 1.43 / 1.33 -- it pays most where a small shard leaves 2-4 waves per SIMD and the step's dependent chain is
-    // exposed. (Round 1 measured the same re-ordering slower, 13.76 against 13.4 ms: that was with flat_load lookups.)
-#ifndef MCX_MH_BATCH
-#define MCX_MH_BATCH MCX_W_STATE
-#endif
     for (; it + 1u <= total_steps; it += 2u) {
         float z0, z1;
         mcx_box_muller(mcx_pcg_out(st_prop), mcx_pcg_angle(st_prop + MCX_STATE_STEP), z0, z1);
@@ -841,15 +856,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #if MCX_MH_BATCH
         const u32 ha0 = mcx_pcg_out(st_acc), ha1 = mcx_pcg_out(st_acc + MCX_STATE_STEP);
         st_acc += 2u * MCX_STATE_STEP;
-        const float x0 = MCX_AFFINE(z0), x1 = MCX_AFFINE(z1);
-        const float lp0 = MCX_LOGP(lp_tb, x0), lp1 = MCX_LOGP(lp_tb, x1);
-#if MCX_Q_SAMPLER
-        const float w0 = fmaf(0.5f * z0, z0, lp0), w1 = fmaf(0.5f * z1, z1, lp1);
-#else
-        const float w0 = lp0 - MCX_LOGQ(lq_tb, x0), w1 = lp1 - MCX_LOGQ(lq_tb, x1);
-#endif
-        mh_finish(it, x0, w0, 0.0f, w0 - cur_lp, ha0);
-        mh_finish(it + 1u, x1, w1, 0.0f, w1 - cur_lp, ha1);
+        mh_two_steps(it, z0, z1, ha0, ha1);
 #else
         mh_step(it, z0);
         mh_step(it + 1u, z1);
