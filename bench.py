@@ -290,12 +290,12 @@ def timed_loop(torch, dist, world, wl, prepared, n_step, out, warmup, steps, n_s
     return elapsed, n_eff
 
 
-def accuracy(np, wl, out_rows, n_eff, n_steps_mcmc=10_000, n_burnin=1_000):
+def accuracy(np, wl, out_rows, n_eff):
     """|mean - truth| against the 3-sigma band for every timed step. out_rows: [steps, rows] all-rank sums."""
     means = out_rows / float(n_eff)
-    if wl.name == "c4":
-        total_chains = n_eff // n_steps_mcmc
-        accept = float(np.mean(out_rows[:, wl.k]) / (float(total_chains) * (n_steps_mcmc + n_burnin)))
+    if wl.n_steps:                                   # MCMC: row k holds the accepted steps (burn-in included)
+        total_chains = n_eff // wl.n_steps
+        accept = float(np.mean(out_rows[:, wl.k]) / (float(total_chains) * (wl.n_steps + wl.n_burnin)))
         truth, band = wl.band(n_eff, accept)
     else:
         accept = None

@@ -89,9 +89,10 @@ class Workload:
     `scale` x the config's nominal size; units(n_eff) = what one step processed in the metric's unit;
     check(sums / n_eff, n_eff) -> (abs_err, three_sigma) per function."""
 
-    def __init__(self, name, title, unit, k, rows, nominal, prepare, launch, units, band, blocking):
+    def __init__(self, name, title, unit, k, rows, nominal, prepare, launch, units, band, blocking, n_steps=0, n_burnin=0):
         self.name, self.title, self.unit, self.k, self.rows, self.nominal = name, title, unit, k, rows, nominal
         self.prepare, self.launch, self.units, self.band, self.blocking = prepare, launch, units, band, blocking
+        self.n_steps, self.n_burnin = n_steps, n_burnin          # MCMC configs: steps per chain
 
 
 def get(name: str, Distribution) -> Workload:
@@ -149,7 +150,8 @@ def get(name: str, Distribution) -> Workload:
             units=lambda n_eff: (n_eff // n_steps) * (n_steps + n_burnin),
             band=band,
             blocking=lambda mc, n, seed: mc.integrate_mcmc(fns, target, proposal, n_steps=n_steps, n_chains=n,
-                                                           n_burnin=n_burnin, seed=seed))
+                                                           n_burnin=n_burnin, seed=seed),
+            n_steps=n_steps, n_burnin=n_burnin)
     if name == "c5":
         dist = Distribution.beta(2.0, 5.0)
         fns = moment_functions(32)

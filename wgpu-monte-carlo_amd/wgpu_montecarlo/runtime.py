@@ -11,6 +11,7 @@ import atexit
 import ctypes as C
 import os
 import threading
+import weakref
 from pathlib import Path
 from typing import Optional
 
@@ -334,8 +335,6 @@ def hip_runtime() -> str:
 
 
 # ---- handles ---------------------------------------------------------------------------------------
-import weakref  # noqa: E402
-
 _live_engines = weakref.WeakSet()
 _live_comms = weakref.WeakSet()
 
