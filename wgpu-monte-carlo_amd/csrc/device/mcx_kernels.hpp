@@ -724,8 +724,17 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #else
         const bool take = ln_u < log_alpha;
 #endif
+#ifndef MCX_MASKED_STATE_UPDATE
+#define MCX_MASKED_STATE_UPDATE 0      // 1: exec-masked v_mov (full rate) instead of v_cndmask (half rate). Measured on C4:
+                                       // slower, 9.57 against 9.21 ms (131 072 chains: 1.98 / 1.74): the scalar mask handling and
+                                       // the branch cost more than the two half-rate selects save
+#endif
+#if MCX_MASKED_STATE_UPDATE && MCX_W_STATE
+        if (take) asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "+v"(cur_x), "+v"(cur_lp) : "v"(prop_x), "v"(prop_lp));
+#else
         cur_x = take ? prop_x : cur_x;
         cur_lp = take ? prop_lp : cur_lp;
+#endif
 #if MCX_WALK == 0 && !MCX_W_STATE
         cur_lq = take ? prop_lq : cur_lq;
 #else
