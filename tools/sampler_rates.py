@@ -30,7 +30,11 @@ def main():
         mc = MonteCarloIntegrator(rng=rng)
         for name, dist in cases:
             best, res = None, None
-            for _ in range(4):
+            # device warm-up: a GPU fresh from idle runs its first tens of milliseconds on a low clock state
+            # (bench.py --prewarm-ms); 60 calls of 0.6-2.8 ms each before the timed ones
+            for _ in range(60):
+                mc.integrate([f1, f2, f3, f4], dist, n_samples=n)
+            for _ in range(6):
                 res = mc.integrate([f1, f2, f3, f4], dist, n_samples=n)
                 k = res.meta["kernel_ms"]
                 best = k if best is None else min(best, k)

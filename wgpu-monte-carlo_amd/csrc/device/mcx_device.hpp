@@ -188,10 +188,12 @@ MCX_DEV void mcx_box_muller(u32 h1, u32 h2, float& z0, float& z1) {
 #ifndef MCX_TABLES_LDS
 #define MCX_TABLES_LDS 1
 #endif
+#ifndef MCX_TBL                      // (MCX_EXTRA_DEFINES="MCX_TBL=" rebuilds the round-1 generic-pointer code for A/B runs)
 #if MCX_TABLES_LDS
 #define MCX_TBL __attribute__((address_space(3)))
 #else
 #define MCX_TBL
+#endif
 #endif
 struct McxTable {
     const MCX_TBL float2* kv;     // LDS or global
