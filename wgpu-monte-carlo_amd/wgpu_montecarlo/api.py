@@ -390,8 +390,9 @@ class MonteCarloIntegrator:
     def _cdf_direct(self, cdf: Optional[runtime.Table], k: int) -> bool:
         """Sample a custom distribution through the bucket-direct form of its CDF table (one read + one FMA for draws
         whose bucket holds no cdf node, the rest resolved in batches) when the table has one; math="precise" keeps the
-        reference's search + blend. Measured on Beta(2,5), 2e9 samples: 1.59 ms against 1.78 ms for the guided search at
-        K = 4, 2.22 / 2.35 ms at K = 16, 3.27 / 3.23 ms at K = 32 (the evaluation dominates there): used up to 16 rows."""
+        reference's search + blend. Measured on Beta(2,5), 2e9 samples, warm device: 1.42 ms against 1.63 ms for the guided
+        search at K = 4, 1.92 / 2.05 ms at K = 16, 2.79 / 2.77 ms at K = 32 (the evaluation dominates there): used up to
+        16 rows (profiles/r02_cdf_sampler_warm_device_ab.jsonl)."""
         rows = k * (2 if self._std_error else 1)
         return (cdf is not None and cdf.direct_bits > 0 and not self._precise_sampler and self._rng == runtime.RNG_PCG_REF
                 and rows <= 16 and not os.environ.get("MCX_NO_DIRECT"))
