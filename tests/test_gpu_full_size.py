@@ -148,15 +148,17 @@ def test_c5_oracle_parity_at_1e8(math, tol):
     assert np.all(err <= tol * np.abs(want) + tol * 1e-2), (math, err / np.abs(want))
 
 
-@pytest.mark.parametrize("case", ["beta-4", "beta-16", "laplace-4"])
+@pytest.mark.parametrize("case", ["beta-4", "beta-16", "beta-32", "laplace-4", "philox-beta-4", "philox-beta-32", "philox-laplace-12"])
 def test_bucket_direct_sampler_oracle_parity_at_1e8(case):
-    """The bucket-direct + queue form of the CDF sampler (K <= 16 rows, reference stream) at 1e8 samples against the
-    oracle's capped search + blend on the same stream: same cell for every draw, the cell's line evaluated on the
-    unrounded low hash bits. Laplace on (-12, 12): both tails flat, x of both signs. Bound: 2e-5 of
-    the magnitude E|x|^k of the summed terms (1 for Beta on [0, 1], k! for the unit Laplace)."""
+    """The bucket-direct + queue form of the CDF sampler (both streams; append-and-resolve queue below 12 rows, exchange
+    ring from 12, power sums by quads there) at 1e8 samples against the oracle's capped search + blend on the same
+    stream: same cell for every draw, the cell's line evaluated on the unrounded low hash bits. Laplace
+    on (-12, 12): both tails flat, x of both signs. Bound: 2e-5 of the magnitude E|x|^k of the summed terms (1 for Beta
+    on [0, 1], k! for the unit Laplace)."""
     from wgpu_montecarlo import Distribution
 
-    name, k = case.split("-")
+    rng = "philox" if case.startswith("philox-") else "pcg_ref"
+    name, k = case.replace("philox-", "").split("-")
     k = int(k)
     if name == "beta":
         dist, scale = Distribution.beta(2.0, 5.0), np.ones(k)
@@ -164,9 +166,9 @@ def test_bucket_direct_sampler_oracle_parity_at_1e8(case):
         dist = Distribution.from_pdf(lambda x: math.exp(-abs(x)) / 2, support=(-12.0, 12.0))
         scale = np.array([math.factorial(j) for j in range(1, k + 1)], dtype=np.float64)
     fns = bc.moment_functions(k) if k == 4 else [lambda x, j=j: x**j for j in range(1, k + 1)]
-    res = _mc().integrate(fns, dist, n_samples=10**8, seed=7)
+    res = _mc(rng=rng).integrate(fns, dist, n_samples=10**8, seed=7)
     assert res.meta["lds_bytes"] == 8 * 8192 + 16 * 128 * 4              # records + queues: the direct form ran
-    ref = oracle.integrate(ORC_POW(k), oracle.CUSTOM, 0.0, 0.0, n_samples=10**8, seed=7, guard=1,
+    ref = oracle.integrate(ORC_POW(k), oracle.CUSTOM, 0.0, 0.0, n_samples=10**8, seed=7, guard=1, rng=int(rng == "philox"),
                            cdf_table=dist._cdf_table, x_table=dist._x_table)
     assert res.meta["n_eff"] == ref["n_eff"]
     want = ref["sums"] / ref["n_eff"]
@@ -174,7 +176,8 @@ def test_bucket_direct_sampler_oracle_parity_at_1e8(case):
     assert np.all(err <= 2e-5 * scale), (case, err / scale)
 
 
-def test_bucket_direct_sampler_equals_the_guided_search(monkeypatch):
+@pytest.mark.parametrize("rng", ["pcg_ref", "philox"])
+def test_bucket_direct_sampler_equals_the_guided_search(monkeypatch, rng):
     """Same draws, same cells: the bucket-direct + queue form against the guided search (MCX_NO_DIRECT=1) on the same
     stream, for plain moments, second moments (std_error: 2K rows), a general (non-polynomial) integrand whose value
     at the flagged lanes' placeholder x would be wrong if it leaked into a sum, and importance sampling with a custom
@@ -192,19 +195,37 @@ def test_bucket_direct_sampler_equals_the_guided_search(monkeypatch):
                                             beta, n_samples=20_000_001, seed=4)
         out["is"] = mc_plain.integrate_importance_sampling([lambda x: x, lambda x: x * x], Distribution.normal(0.0, 1.0), lap,
                                                            n_samples=20_000_001, seed=5)
+        # >= 12 rows: the exchange ring (flagged lanes evaluate an earlier resolved sample instead of sitting out)
+        out["general12"] = mc_plain.integrate([lambda x: 1.0 / (x + 0.25), lambda x: math.cos(3.0 * x) + 2.0, lambda x: x > 0.5,
+                                               lambda x: math.exp(-x), lambda x: math.sqrt(x + 1.0), lambda x: x * x,
+                                               lambda x: math.sin(x) + 1.0, lambda x: (x - 0.3) * (x - 0.3), lambda x: 1.0,
+                                               lambda x: x, lambda x: x * x * x, lambda x: math.exp(x)],
+                                              beta, n_samples=20_000_001, seed=6)
+        out["is12"] = mc_plain.integrate_importance_sampling([lambda x, j=j: x**j for j in range(1, 13)],
+                                                             Distribution.normal(0.0, 1.0), lap, n_samples=20_000_001, seed=8)
+        out["second8"] = mc_se.integrate([lambda x, j=j: x**j for j in range(1, 9)], beta, n_samples=20_000_001, seed=3)
+        # sizes that leave 1, 2, 3 iterations for the last pass (odd tails, the partial Philox call)
+        for n in (999_999, 65_536 * 5 + 1, 65_536 * 7 - 1):
+            out[f"moments12_n{n}"] = mc_plain.integrate([lambda x, j=j: x**j for j in range(1, 13)], lap, n_samples=n, seed=9)
+            out[f"moments3_n{n}"] = mc_plain.integrate([lambda x, j=j: x**j for j in range(1, 4)], lap, n_samples=n, seed=9)
         return out
 
-    direct = calls(_mc(), _mc(std_error=True))
+    direct = calls(_mc(rng=rng), _mc(rng=rng, std_error=True))
     assert direct["moments"].meta["lds_bytes"] == 8 * 8192 + 16 * 128 * 4
     monkeypatch.setenv("MCX_NO_DIRECT", "1")
-    guided = calls(_mc(), _mc(std_error=True))
+    guided = calls(_mc(rng=rng), _mc(rng=rng, std_error=True))
     assert guided["moments"].meta["lds_bytes"] != direct["moments"].meta["lds_bytes"]
     for key in direct:
         a, b = direct[key], guided[key]
         assert a.meta["n_eff"] == b.meta["n_eff"]
-        assert np.allclose(a.values, b.values, rtol=3e-6, atol=3e-6), (key, a.values, b.values)
+        # the ring puts different draws into one lane's pair / quad than the guided search does: the rounding of the
+        # power-sum recurrences differs
+        tol = 3e-5 if key.startswith(("is12", "moments12")) else 3e-6
+        assert np.allclose(a.values, b.values, rtol=tol, atol=tol), (key, a.values, b.values)
     assert np.allclose(direct["second"].meta["std_error"], guided["second"].meta["std_error"], rtol=1e-4)
+    assert np.allclose(direct["second8"].meta["std_error"], guided["second8"].meta["std_error"], rtol=1e-4)
     assert abs(direct["general"].values[2] - 0.109375) < 1e-3          # P(Beta(2,5) > 0.5) = 7/64
+    assert abs(direct["general12"].values[8] - 1.0) < 1e-6             # every draw evaluated exactly once
 
 
 @pytest.mark.parametrize("math,tol", [("default", 2e-4), ("precise", 2e-4)])

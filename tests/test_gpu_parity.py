@@ -478,8 +478,8 @@ def test_philox_mcmc_matches_its_oracle(kind):
 @pytest.mark.parametrize("case", ["beta_k32", "normal_k12", "is_table_k9", "philox_uniform_k16"])
 def test_moment_family_pairs_match_per_sample_evaluation(integrator, case):
     """desc.moment_family: x, x**2, .., x**K accumulated two samples at a time through Newton's identity
-    s_k = (a + b) s_{k-1} - a b s_{k-2} against the per-sample multiply chain on the same stream, and against the
-    oracle. Sums of powers of samples of mixed sign cancel in both forms; the bound is relative to sum |x|^k."""
+    s_k = (a + b) s_{k-1} - a b s_{k-2} (below 12 rows on the reference stream), four at a time through the recurrence of
+    their quartic above, against the per-sample multiply chain on the same stream, and against the oracle. Sums of powers of samples of mixed sign cancel in both forms; the bound is relative to sum |x|^k."""
     from wgpu_montecarlo import Distribution, MonteCarloIntegrator
     from wgpu_montecarlo import runtime as rt
     from wgpu_montecarlo.api import _moment_family, functions_to_hip

@@ -259,6 +259,15 @@ MCX_DEV void mcx_accumulate_z(float z, float x, const McxParamsV& pv, const McxI
     mcx_eval_all<S>(x, mcx_weight_z(z, x, pv, tb), acc);
 }
 
+// MCX_MOMENT_QUAD: the moment family takes four samples per trip through mcx_eval_quad (1.25 VALU per power per sample
+// against 1.5 for pairs); what is left of a flush block (at most one pair and one single) goes the pair way.
+// Measured (2e9 samples, warm): reference stream, Beta(2,5) 16 / 32 rows 1.86 -> 1.77 / 2.70 -> 2.48 ms, N(0,1) 16 / 32 rows
+// 1.46 -> 1.45 / 2.31 -> 2.25 ms, but 8 rows 0.99 -> 1.11 ms (set-up outweighs the saving): from 12 rows. The Philox loop
+// has the four outputs of one call at hand and otherwise evaluates per sample: always.
+#ifndef MCX_MOMENT_QUAD
+#define MCX_MOMENT_QUAD (MCX_MOMENT_FAMILY && (MCX_K >= 12 || MCX_RNG == 1))
+#endif
+
 // Two samples at once. MCX_MOMENT_FAMILY (user_func_i(x) = x^(i+1), promised by the caller): the generated
 // mcx_eval_pair accumulates the weighted power sums wa a^k + wb b^k through Newton's identity into the first
 // accumulator set; otherwise each sample goes through mcx_eval_all into its own set.
@@ -292,7 +301,18 @@ MCX_DEV float mcx_draw(u32 h, const McxParamsV& pv, const McxTable& cdf_tb) {
 #endif
 }
 
-extern "C" __global__ void __launch_bounds__(MCX_BLOCK)
+// 1024-thread workgroups are chosen so that more waves share one staged copy of the tables; two of them fit a CU only
+// with <= 64 VGPRs per lane (8 waves per SIMD). Hold the register allocator to that (K = 32 moments on a CDF table with
+// the Philox stream: 66 VGPRs and 3.53 ms per 2e9 samples without, 2.87 ms with).
+#ifndef MCX_INTEGRATE_ATTR
+#if MCX_BLOCK == 1024 && MCX_TABLES_LDS
+#define MCX_INTEGRATE_ATTR __attribute__((amdgpu_waves_per_eu(8)))
+#else
+#define MCX_INTEGRATE_ATTR
+#endif
+#endif
+#if !defined(MCX_KIND) || MCX_KIND == 0          // a module holds the kernel of its kind (+ the fold kernel)
+extern "C" __global__ void __launch_bounds__(MCX_BLOCK) MCX_INTEGRATE_ATTR
 mcx_integrate_kernel(McxIntegrateArgs a) {
     const McxParamsV pv = mcx_params_v(a);
     (void)pv;
@@ -364,83 +384,16 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         _Pragma("unroll") for (int k = 0; k < MCX_K * MCX_ACC_S; ++k) acc[k] = 0.0f;                 \
     } while (0)
 
-#if MCX_RNG == 1
-    // Philox stream: unit = one Philox call j = iterations 4j .. 4j+3 (two Box-Muller pairs for the normal)
-    auto philox_sample = [&](u32 h_first, u32 h_second, u32 n_valid) {
-        // consumes two outputs = two iterations; n_valid in {1, 2} of them exist (i < L)
-#if MCX_DIST == MCX_DIST_NORMAL
-        float z0, z1;
-        mcx_box_muller(h_first, h_second, z0, z1);
-        mcx_accumulate_z<MCX_ACC_S>(z0, MCX_AFFINE(z0), pv, is_tb, acc);
-        if (n_valid > 1u) mcx_accumulate_z<MCX_ACC_S>(z1, MCX_AFFINE(z1), pv, is_tb, acc + (MCX_ACC_S - 1));
-#else
-        mcx_accumulate<MCX_ACC_S>(mcx_draw(h_first, pv, cdf_tb), is_tb, acc);
-        if (n_valid > 1u) mcx_accumulate<MCX_ACC_S>(mcx_draw(h_second, pv, cdf_tb), is_tb, acc + (MCX_ACC_S - 1));
-#endif
-    };
-    const u32 full_quads = a.loops_per_thread >> 2;          // calls whose four iterations all exist
-    const u32 e_full = u1 < full_quads ? u1 : full_quads;
-    u32 j = u0;
-    while (j < e_full) {
-        u32 blk_end = j + MCX_FLUSH / 2u;
-        blk_end = blk_end < e_full ? blk_end : e_full;
-        MCX_ZERO_ACC();
-        for (; j < blk_end; ++j) {
-            const McxU4 o = mcx_philox4x32_10(McxU4{idx, j, 0u, 0u}, a.seed, MCX_PHILOX_KEY1);
-            philox_sample(o.x, o.y, 2u);
-            philox_sample(o.z, o.w, 2u);
-        }
-        MCX_FLUSH_ACC();
-    }
-    if (active && u1 > full_quads) {                          // the last, partial call: 1..3 iterations left
-        const u32 rem = a.loops_per_thread - 4u * full_quads;
-        const McxU4 o = mcx_philox4x32_10(McxU4{idx, full_quads, 0u, 0u}, a.seed, MCX_PHILOX_KEY1);
-        MCX_ZERO_ACC();
-        philox_sample(o.x, o.y, rem >= 2u ? 2u : 1u);
-        if (rem == 3u) philox_sample(o.z, o.w, 1u);
-        MCX_FLUSH_ACC();
-    }
-#elif MCX_DIST == MCX_DIST_NORMAL
-    // unit = Box-Muller pair j: iterations (2j, 2j+1), counters (4j, 4j+1) (distribution.rs:97-98)
-    const u32 full_pairs = a.loops_per_thread >> 1;          // pairs whose second half is used
-    const u32 e_full = u1 < full_pairs ? u1 : full_pairs;
-    u32 st = mcx_state(a.seed, idx, 4u * u0);
-    u32 j = u0;
-    while (j < e_full) {
-        u32 blk_end = j + MCX_FLUSH;
-        blk_end = blk_end < e_full ? blk_end : e_full;
-        MCX_ZERO_ACC();
-#pragma unroll mcx_unroll
-        for (; j < blk_end; ++j) {
-            u32 h1 = mcx_pcg_out(st);
-            u32 h2 = mcx_pcg_angle(st + MCX_STATE_STEP);
-            st += 4u * MCX_STATE_STEP;
-            float z0, z1;
-            mcx_box_muller(h1, h2, z0, z1);
-            const float xa = MCX_AFFINE(z0), xb = MCX_AFFINE(z1);
-            mcx_accumulate_pair<MCX_ACC_S>(xa, xb, mcx_weight_z(z0, xa, pv, is_tb), mcx_weight_z(z1, xb, pv, is_tb), acc);
-        }
-        MCX_FLUSH_ACC();
-    }
-    if (active && u1 > full_pairs) {
-        // L odd: the last pair contributes z0 only, z1 is discarded (shader_gen.rs:105-112)
-        st = mcx_state(a.seed, idx, 4u * full_pairs);
-        u32 h1 = mcx_pcg_out(st);
-        u32 h2 = mcx_pcg_angle(st + MCX_STATE_STEP);
-        float z0, z1;
-        mcx_box_muller(h1, h2, z0, z1);
-        MCX_ZERO_ACC();
-        mcx_accumulate_z<MCX_ACC_S>(z0, MCX_AFFINE(z0), pv, is_tb, acc);
-        MCX_FLUSH_ACC();
-    }
-#elif MCX_CDF_DIRECT
-    // unit = iteration i, counter i (distribution.rs:333). Bucket-direct sampling: a draw whose bucket holds no cdf node
-    // is one 8-byte LDS read + one FMA. The others (17 % on Beta(2,5) at 8192 buckets) would make EVERY wave walk the
-    // search path for a few lanes each iteration; instead their hash words are appended to a per-wave LDS queue
-    // (one v_cmp per sample gives the ballot, mbcnt the slots) and resolved 64 at a time with all lanes busy.
-    // The sum does not care which lane, or which flush block, a sample is added in; every draw of the grid is still
-    // evaluated exactly once. (Measured and not kept: requesting the records of pair p + 1 before evaluating pair p,
-    // and one combined append per pair -- 1.61 ms against 1.59 ms per 2e9 samples at K = 4, and 4 KiB more LDS.)
+#if MCX_CDF_DIRECT
+    // Bucket-direct sampling: a draw whose bucket holds no cdf node is one 8-byte LDS read + one FMA. The others (17 % on
+    // Beta(2,5) at 8192 buckets) would make EVERY wave walk the search path for a few lanes each iteration; instead their
+    // hash words go to a per-wave LDS queue (one v_cmp per sample gives the ballot, mbcnt the slots) and are resolved 64
+    // at a time with all lanes busy. The sum does not care which lane, or which flush block, a sample is added in; every
+    // draw of the grid is still evaluated exactly once. (Measured and not kept: requesting the records of pair p + 1
+    // before evaluating pair p, and one combined append per pair -- 1.61 ms against 1.59 ms per 2e9 samples at K = 4, and
+    // 4 KiB more LDS.) Interface to the loops below, both streams:
+    //   direct_pair(hA, hB, xA, xB, lA, lB) / direct_one(h, x, l): x = the sample to evaluate in this lane now, l = there
+    //   is one (false: evaluate nothing here); direct_finish(): evaluates what the queue still holds.
 #ifndef MCX_QCAP
 #define MCX_QCAP 128u                 // <= 63 left over + 64 appended
 #endif
@@ -450,6 +403,76 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
     __attribute__((address_space(3))) u32* const queue =
         (__attribute__((address_space(3))) u32*)(mcx_lds_raw + lds_off) + (threadIdx.x >> 6) * MCX_QCAP;
     const u32 lane_id = threadIdx.x & 63u;
+#ifndef MCX_DIRECT_SWAP
+#define MCX_DIRECT_SWAP (MCX_K >= 12)        // measured: 8 rows neutral, 16 rows + 4 %, 32 rows + 9 %
+#endif
+#if MCX_DIRECT_SWAP
+    // Many rows: the evaluation is the expensive part, and a flagged lane sitting it out (and being evaluated again in the
+    // resolve step) wastes it. Here the queue is a ring of 128 words that holds hash words on their way in and resolved
+    // samples on their way out, never both in one slot: a flagged lane EXCHANGES its hash word for the sample resolved
+    // in that slot one lap (128 flagged draws) earlier and evaluates that instead -- every lane of every trip evaluates
+    // a real sample, the resolve step only searches. Whenever the write position crosses a 64-slot boundary the block
+    // just completed is resolved in place by all 64 lanes. Slots that were never written hold MCX_RING_EMPTY; at the
+    // end the partial block is resolved and all 128 slots are evaluated.
+#if MCX_MOMENT_FAMILY && !MCX_WEIGHT
+#define MCX_RING_EMPTY 0x07000000u       // 9.6e-35f: its powers add nothing to the power sums, no mask needed
+#define MCX_RING_LIVE(bits) true
+#else
+#define MCX_RING_EMPTY 0xFFFFFFFFu       // a NaN pattern no resolved sample has
+#define MCX_RING_LIVE(bits) ((bits) != MCX_RING_EMPTY)
+#endif
+    queue[lane_id] = MCX_RING_EMPTY;
+    queue[lane_id + 64u] = MCX_RING_EMPTY;
+    u32 r_pos = 0u;                   // wave-uniform write position, 0..127
+    auto resolve = [&](u32 base, u32 take) {
+        __builtin_amdgcn_wave_barrier();
+        if (lane_id < take) {
+            const u32 h = queue[base + lane_id];
+            const float2 r = cd.rec[h >> cd.shift];
+            queue[base + lane_id] =
+                __builtin_bit_cast(u32, mcx_cdf_search_window(cd, __builtin_bit_cast(u32, r.x), (float)h * 0x1.0p-32f));
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // flagged lanes (ballot m): hash word in, an earlier resolved sample out (x, live = it is one)
+    auto swap_in = [&](u64 m, bool flagged, u32 h, float& x, bool& live) {
+        const u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, r_pos));
+        if (flagged) {
+            const u32 old = __hip_atomic_exchange(&queue[pos & 127u], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            live = MCX_RING_LIVE(old);
+            x = live ? __builtin_bit_cast(float, old) : 0.0f;          // never hand the NaN pattern on (0 * NaN in a weighted sum)
+        }
+        const u32 np = r_pos + (u32)__builtin_popcountll(m);
+        if ((np ^ r_pos) & 64u) resolve(r_pos & 64u, 64u);
+        r_pos = np & 127u;
+    };
+    auto direct_one = [&](u32 h, float& x, bool& l) {
+        const float2 r = cd.rec[h >> cd.shift];
+        const u64 m = mcx_cdf_flag_mask(r);
+        const bool f = mcx_inverse_ballot(m);
+        x = mcx_cdf_line(cd, r, h);
+        l = true;
+        swap_in(m, f, h, x, l);
+    };
+    auto direct_pair = [&](u32 hA, u32 hB, float& xA, float& xB, bool& lA, bool& lB) {
+        const float2 rA = cd.rec[hA >> cd.shift];
+        const float2 rB = cd.rec[hB >> cd.shift];
+        const u64 mA = mcx_cdf_flag_mask(rA), mB = mcx_cdf_flag_mask(rB);
+        const bool fA = mcx_inverse_ballot(mA), fB = mcx_inverse_ballot(mB);
+        xA = mcx_cdf_line(cd, rA, hA), xB = mcx_cdf_line(cd, rB, hB);
+        lA = true, lB = true;
+        swap_in(mA, fA, hA, xA, lA);
+        swap_in(mB, fB, hB, xB, lB);
+    };
+    auto direct_finish = [&]() {                             // the partial block, then everything still in the ring
+        if (r_pos & 63u) resolve(r_pos & 64u, r_pos & 63u);
+        const u32 bA = queue[lane_id], bB = queue[lane_id + 64u];
+        MCX_ZERO_ACC();
+        if (MCX_RING_LIVE(bA)) mcx_accumulate<MCX_ACC_S>(__builtin_bit_cast(float, bA), is_tb, acc);
+        if (MCX_RING_LIVE(bB)) mcx_accumulate<MCX_ACC_S>(__builtin_bit_cast(float, bB), is_tb, acc + (MCX_ACC_S - 1));
+        MCX_FLUSH_ACC();
+    };
+#else
     u32 q_count = 0u;                 // wave-uniform
     // resolve the newest `take` (<= 64) queued draws, one per lane: the reference's search inside the bucket's window
     auto resolve = [&](u32 take) {
@@ -475,51 +498,215 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
             if (q_count >= 64u) resolve(64u);
         }
     };
+    // a flagged lane sits the evaluation out (l = false; its x is ~1e-34, mcx_cdf_line); its draw is evaluated in resolve
+    auto direct_one = [&](u32 h, float& x, bool& l) {
+        const float2 r = cd.rec[h >> cd.shift];
+        const u64 m = mcx_cdf_flag_mask(r);
+        const bool f = mcx_inverse_ballot(m);
+        x = mcx_cdf_line(cd, r, h);
+        l = !f;
+        defer(m, f, h);
+    };
+    auto direct_pair = [&](u32 hA, u32 hB, float& xA, float& xB, bool& lA, bool& lB) {
+        const float2 rA = cd.rec[hA >> cd.shift];
+        const float2 rB = cd.rec[hB >> cd.shift];
+        const u64 mA = mcx_cdf_flag_mask(rA), mB = mcx_cdf_flag_mask(rB);
+        const bool fA = mcx_inverse_ballot(mA), fB = mcx_inverse_ballot(mB);
+        xA = mcx_cdf_line(cd, rA, hA), xB = mcx_cdf_line(cd, rB, hB);
+        lA = !fA, lB = !fB;
+        defer(mA, fA, hA);
+        defer(mB, fB, hB);
+    };
+    auto direct_finish = [&]() {                             // what is left in the queue (< 64 draws)
+        if (q_count != 0u) {
+            MCX_ZERO_ACC();
+            resolve(q_count);
+            MCX_FLUSH_ACC();
+        }
+    };
+#endif
+    // evaluation of what direct_pair / direct_one handed out. Moment family without weights: a lane without a sample
+    // carries x ~ 1e-34, whose powers add nothing -- no masking; with weights its weight is forced to 0.
+#define MCX_LIVE_WEIGHT(l, x) (MCX_WEIGHT ? ((l) ? mcx_weight(x, is_tb) : 0.0f) : 1.0f)
+    auto direct_eval_pair = [&](float xA, float xB, bool lA, bool lB) {
+#if MCX_MOMENT_FAMILY
+        mcx_accumulate_pair<MCX_ACC_S>(xA, xB, MCX_LIVE_WEIGHT(lA, xA), MCX_LIVE_WEIGHT(lB, xB), acc);
+#else
+        if (lA) mcx_accumulate<MCX_ACC_S>(xA, is_tb, acc);
+        if (lB) mcx_accumulate<MCX_ACC_S>(xB, is_tb, acc + (MCX_ACC_S - 1));
+#endif
+    };
+#if MCX_MOMENT_QUAD
+    auto direct_eval_quad = [&](float xA, float xB, float xC, float xD, bool lA, bool lB, bool lC, bool lD) {
+        mcx_eval_quad<MCX_ACC_S>(xA, xB, xC, xD, MCX_LIVE_WEIGHT(lA, xA), MCX_LIVE_WEIGHT(lB, xB), MCX_LIVE_WEIGHT(lC, xC),
+                                 MCX_LIVE_WEIGHT(lD, xD), acc);
+    };
+#endif
+#endif          // MCX_CDF_DIRECT
+
+#if MCX_RNG == 1
+    // Philox stream: unit = one Philox call j = iterations 4j .. 4j+3 (two Box-Muller pairs for the normal)
+    auto philox_sample = [&](u32 h_first, u32 h_second, u32 n_valid) {
+        // consumes two outputs = two iterations; n_valid in {1, 2} of them exist (i < L)
+#if MCX_DIST == MCX_DIST_NORMAL
+        float z0, z1;
+        mcx_box_muller(h_first, h_second, z0, z1);
+        mcx_accumulate_z<MCX_ACC_S>(z0, MCX_AFFINE(z0), pv, is_tb, acc);
+        if (n_valid > 1u) mcx_accumulate_z<MCX_ACC_S>(z1, MCX_AFFINE(z1), pv, is_tb, acc + (MCX_ACC_S - 1));
+#elif MCX_CDF_DIRECT
+        float x;
+        bool l;
+        direct_one(h_first, x, l);
+        if (l) mcx_accumulate<MCX_ACC_S>(x, is_tb, acc);
+        if (n_valid > 1u) {                                   // wave-uniform
+            direct_one(h_second, x, l);
+            if (l) mcx_accumulate<MCX_ACC_S>(x, is_tb, acc + (MCX_ACC_S - 1));
+        }
+#else
+        mcx_accumulate<MCX_ACC_S>(mcx_draw(h_first, pv, cdf_tb), is_tb, acc);
+        if (n_valid > 1u) mcx_accumulate<MCX_ACC_S>(mcx_draw(h_second, pv, cdf_tb), is_tb, acc + (MCX_ACC_S - 1));
+#endif
+    };
+    const u32 full_quads = a.loops_per_thread >> 2;          // calls whose four iterations all exist
+    const u32 e_full = u1 < full_quads ? u1 : full_quads;
+    u32 j = u0;
+    while (j < e_full) {
+        u32 blk_end = j + MCX_FLUSH / 2u;
+        blk_end = blk_end < e_full ? blk_end : e_full;
+        MCX_ZERO_ACC();
+        for (; j < blk_end; ++j) {
+            const McxU4 o = mcx_philox4x32_10(McxU4{idx, j, 0u, 0u}, a.seed, MCX_PHILOX_KEY1);
+#if MCX_CDF_DIRECT
+            float xa, xb, xc, xd;
+            bool la, lb, lc, ld;
+            direct_pair(o.x, o.y, xa, xb, la, lb);
+            direct_pair(o.z, o.w, xc, xd, lc, ld);
+#if MCX_MOMENT_QUAD
+            direct_eval_quad(xa, xb, xc, xd, la, lb, lc, ld);
+#else
+            direct_eval_pair(xa, xb, la, lb);
+            direct_eval_pair(xc, xd, lc, ld);
+#endif
+#elif MCX_MOMENT_QUAD
+            // the four outputs of one call are one quad of the moment family
+#if MCX_DIST == MCX_DIST_NORMAL
+            float z0, z1, z2, z3;
+            mcx_box_muller(o.x, o.y, z0, z1);
+            mcx_box_muller(o.z, o.w, z2, z3);
+            const float xa = MCX_AFFINE(z0), xb = MCX_AFFINE(z1), xc = MCX_AFFINE(z2), xd = MCX_AFFINE(z3);
+            mcx_eval_quad<MCX_ACC_S>(xa, xb, xc, xd, mcx_weight_z(z0, xa, pv, is_tb), mcx_weight_z(z1, xb, pv, is_tb),
+                                     mcx_weight_z(z2, xc, pv, is_tb), mcx_weight_z(z3, xd, pv, is_tb), acc);
+#else
+            const float xa = mcx_draw(o.x, pv, cdf_tb), xb = mcx_draw(o.y, pv, cdf_tb);
+            const float xc = mcx_draw(o.z, pv, cdf_tb), xd = mcx_draw(o.w, pv, cdf_tb);
+            mcx_eval_quad<MCX_ACC_S>(xa, xb, xc, xd, mcx_weight(xa, is_tb), mcx_weight(xb, is_tb), mcx_weight(xc, is_tb),
+                                     mcx_weight(xd, is_tb), acc);
+#endif
+#else
+            philox_sample(o.x, o.y, 2u);
+            philox_sample(o.z, o.w, 2u);
+#endif
+        }
+        MCX_FLUSH_ACC();
+    }
+    if (active && u1 > full_quads) {                          // the last, partial call: 1..3 iterations left
+        const u32 rem = a.loops_per_thread - 4u * full_quads;
+        const McxU4 o = mcx_philox4x32_10(McxU4{idx, full_quads, 0u, 0u}, a.seed, MCX_PHILOX_KEY1);
+        MCX_ZERO_ACC();
+        philox_sample(o.x, o.y, rem >= 2u ? 2u : 1u);
+        if (rem == 3u) philox_sample(o.z, o.w, 1u);
+        MCX_FLUSH_ACC();
+    }
+#if MCX_CDF_DIRECT
+    direct_finish();
+#endif
+#elif MCX_DIST == MCX_DIST_NORMAL
+    // unit = Box-Muller pair j: iterations (2j, 2j+1), counters (4j, 4j+1) (distribution.rs:97-98)
+    const u32 full_pairs = a.loops_per_thread >> 1;          // pairs whose second half is used
+    const u32 e_full = u1 < full_pairs ? u1 : full_pairs;
+    u32 st = mcx_state(a.seed, idx, 4u * u0);
+    u32 j = u0;
+    while (j < e_full) {
+        u32 blk_end = j + MCX_FLUSH;
+        blk_end = blk_end < e_full ? blk_end : e_full;
+        MCX_ZERO_ACC();
+        auto draw_pair = [&](float& xa, float& xb, float& wa, float& wb) {
+            u32 h1 = mcx_pcg_out(st);
+            u32 h2 = mcx_pcg_angle(st + MCX_STATE_STEP);
+            st += 4u * MCX_STATE_STEP;
+            float z0, z1;
+            mcx_box_muller(h1, h2, z0, z1);
+            xa = MCX_AFFINE(z0), xb = MCX_AFFINE(z1);
+            wa = mcx_weight_z(z0, xa, pv, is_tb), wb = mcx_weight_z(z1, xb, pv, is_tb);
+        };
+#if MCX_MOMENT_QUAD
+        for (; j + 1u < blk_end; j += 2u) {
+            float xa, xb, xc, xd, wa, wb, wc, wd;
+            draw_pair(xa, xb, wa, wb);
+            draw_pair(xc, xd, wc, wd);
+            mcx_eval_quad<MCX_ACC_S>(xa, xb, xc, xd, wa, wb, wc, wd, acc);
+        }
+#endif
+#pragma unroll mcx_unroll
+        for (; j < blk_end; ++j) {
+            float xa, xb, wa, wb;
+            draw_pair(xa, xb, wa, wb);
+            mcx_accumulate_pair<MCX_ACC_S>(xa, xb, wa, wb, acc);
+        }
+        MCX_FLUSH_ACC();
+    }
+    if (active && u1 > full_pairs) {
+        // L odd: the last pair contributes z0 only, z1 is discarded (shader_gen.rs:105-112)
+        st = mcx_state(a.seed, idx, 4u * full_pairs);
+        u32 h1 = mcx_pcg_out(st);
+        u32 h2 = mcx_pcg_angle(st + MCX_STATE_STEP);
+        float z0, z1;
+        mcx_box_muller(h1, h2, z0, z1);
+        MCX_ZERO_ACC();
+        mcx_accumulate_z<MCX_ACC_S>(z0, MCX_AFFINE(z0), pv, is_tb, acc);
+        MCX_FLUSH_ACC();
+    }
+#elif MCX_CDF_DIRECT
+    // unit = iteration i, counter i (distribution.rs:333)
     u32 st = mcx_state(a.seed, idx, u0);
     u32 i = u0;
     while (i < u1) {
         u32 blk_end = i + 2u * MCX_FLUSH;
         blk_end = blk_end < u1 ? blk_end : u1;
         MCX_ZERO_ACC();
-#pragma unroll mcx_unroll
-        for (; i + 1u < blk_end; i += 2u) {
+        auto draw_pair = [&](float& xA, float& xB, bool& lA, bool& lB) {
             const u32 hA = mcx_pcg_out(st);
             const u32 hB = mcx_pcg_out(st + MCX_STATE_STEP);
             st += 2u * MCX_STATE_STEP;
-            const float2 rA = cd.rec[hA >> cd.shift];
-            const float2 rB = cd.rec[hB >> cd.shift];
-            const u64 mA = mcx_cdf_flag_mask(rA), mB = mcx_cdf_flag_mask(rB);
-            const bool fA = mcx_inverse_ballot(mA), fB = mcx_inverse_ballot(mB);
-            const float xA = mcx_cdf_line(cd, rA, hA), xB = mcx_cdf_line(cd, rB, hB);
-#if MCX_MOMENT_FAMILY
-            // a flagged lane's x is ~1e-34 (mcx_cdf_line): its powers add nothing to the power sums, so without weights
-            // the pair needs no masking; with importance weights the flagged sample's weight is forced to 0
-            mcx_accumulate_pair<MCX_ACC_S>(xA, xB, MCX_WEIGHT ? (fA ? 0.0f : mcx_weight(xA, is_tb)) : 1.0f,
-                                           MCX_WEIGHT ? (fB ? 0.0f : mcx_weight(xB, is_tb)) : 1.0f, acc);
-#else
-            if (!fA) mcx_accumulate<MCX_ACC_S>(xA, is_tb, acc);
-            if (!fB) mcx_accumulate<MCX_ACC_S>(xB, is_tb, acc + (MCX_ACC_S - 1));
+            direct_pair(hA, hB, xA, xB, lA, lB);
+        };
+#if MCX_MOMENT_QUAD
+        for (; i + 3u < blk_end; i += 4u) {
+            float xA, xB, xC, xD;
+            bool lA, lB, lC, lD;
+            draw_pair(xA, xB, lA, lB);
+            draw_pair(xC, xD, lC, lD);
+            direct_eval_quad(xA, xB, xC, xD, lA, lB, lC, lD);
+        }
 #endif
-            defer(mA, fA, hA);
-            defer(mB, fB, hB);
+#pragma unroll mcx_unroll
+        for (; i + 1u < blk_end; i += 2u) {
+            float xA, xB;
+            bool lA, lB;
+            draw_pair(xA, xB, lA, lB);
+            direct_eval_pair(xA, xB, lA, lB);
         }
         if (i < blk_end) {                                   // odd tail of the block
-            const u32 h = mcx_pcg_out(st);
+            float x;
+            bool l;
+            direct_one(mcx_pcg_out(st), x, l);
             st += MCX_STATE_STEP;
             ++i;
-            const float2 r = cd.rec[h >> cd.shift];
-            const u64 m = mcx_cdf_flag_mask(r);
-            const bool f = mcx_inverse_ballot(m);
-            if (!f) mcx_accumulate<MCX_ACC_S>(mcx_cdf_line(cd, r, h), is_tb, acc);
-            defer(m, f, h);
+            if (l) mcx_accumulate<MCX_ACC_S>(x, is_tb, acc);
         }
         MCX_FLUSH_ACC();
     }
-    if (q_count != 0u) {                                     // what is left in the queue (< 64 draws)
-        MCX_ZERO_ACC();
-        resolve(q_count);
-        MCX_FLUSH_ACC();
-    }
+    direct_finish();
 #else
     // unit = iteration i, counter i (distribution.rs:333); two iterations per trip for the A/B lanes
     u32 st = mcx_state(a.seed, idx, u0);
@@ -528,13 +715,26 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         u32 blk_end = i + 2u * MCX_FLUSH;
         blk_end = blk_end < u1 ? blk_end : u1;
         MCX_ZERO_ACC();
-#pragma unroll mcx_unroll
-        for (; i + 1u < blk_end; i += 2u) {
+        auto draw_pair = [&](float& xA, float& xB) {
             u32 hA = mcx_pcg_out(st);
             u32 hB = mcx_pcg_out(st + MCX_STATE_STEP);
             st += 2u * MCX_STATE_STEP;
-            float xA = mcx_draw(hA, pv, cdf_tb);
-            float xB = mcx_draw(hB, pv, cdf_tb);
+            xA = mcx_draw(hA, pv, cdf_tb);
+            xB = mcx_draw(hB, pv, cdf_tb);
+        };
+#if MCX_MOMENT_QUAD
+        for (; i + 3u < blk_end; i += 4u) {
+            float xA, xB, xC, xD;
+            draw_pair(xA, xB);
+            draw_pair(xC, xD);
+            mcx_eval_quad<MCX_ACC_S>(xA, xB, xC, xD, mcx_weight(xA, is_tb), mcx_weight(xB, is_tb), mcx_weight(xC, is_tb),
+                                     mcx_weight(xD, is_tb), acc);
+        }
+#endif
+#pragma unroll mcx_unroll
+        for (; i + 1u < blk_end; i += 2u) {
+            float xA, xB;
+            draw_pair(xA, xB);
             mcx_accumulate_pair<MCX_ACC_S>(xA, xB, mcx_weight(xA, is_tb), mcx_weight(xB, is_tb), acc);
         }
         if (i < blk_end) {                                   // odd tail of the block
@@ -563,6 +763,8 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 #undef MCX_ACC_B
 #undef MCX_ACC_S
 }
+
+#endif          // MCX_KIND == 0
 
 // =============================================================================================
 // K3: Metropolis-Hastings, one chain per thread. MCX_WALK 0: independent proposals x' ~ q (the reference);
@@ -607,6 +809,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 // One proposal of a non-normal family from one hash output.
 MCX_DEV float mcx_draw_proposal(u32 h, const McxParamsV& pv, const McxTable& cdf_tb) { return mcx_draw(h, pv, cdf_tb); }
 
+#if !defined(MCX_KIND) || MCX_KIND == 1
 extern "C" __global__ void __launch_bounds__(MCX_BLOCK)
 mcx_mcmc_kernel(McxMcmcArgs a) {
     const McxParamsV pv = mcx_params_v(a);
@@ -900,6 +1103,8 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 
     mcx_block_reduce_store<MCX_MCMC_ROWS>(sum, a.partials);
 }
+
+#endif          // MCX_KIND == 1
 
 // =============================================================================================
 // stage 2: fold partials[n_blocks][rows] -> out[rows] in a fixed order (one workgroup per row)

@@ -394,8 +394,8 @@ class MonteCarloIntegrator:
         search at K = 4, 1.92 / 2.05 ms at K = 16, 2.79 / 2.77 ms at K = 32 (the evaluation dominates there): used up to
         16 rows (profiles/r02_cdf_sampler_warm_device_ab.jsonl)."""
         rows = k * (2 if self._std_error else 1)
-        return (cdf is not None and cdf.direct_bits > 0 and not self._precise_sampler and self._rng == runtime.RNG_PCG_REF
-                and rows <= 16 and not os.environ.get("MCX_NO_DIRECT"))
+        return (cdf is not None and cdf.direct_bits > 0 and not self._precise_sampler
+                and rows <= int(os.environ.get("MCX_DIRECT_MAX_ROWS", "32")) and not os.environ.get("MCX_NO_DIRECT"))
 
     def _rank_world(self):
         return (self._group.rank, self._group.world) if self._group is not None else (0, 1)
