@@ -182,6 +182,14 @@ typedef struct mcx_module_desc {
                                 * line evaluated on the unrounded low hash bits (<= 2.4e-7 * slope from the blend on the
                                 * rounded u); other draws run the search inside the bucket's window. The integrate kernel
                                 * additionally defers those draws to a per-wave LDS queue and resolves them 64 at a time. */
+    int32_t cell_noclamp;      /* 1 (with cell_tables and tables_lds; not with user_tables or walk): the cell lookup drops its index
+                                * clamp -- one half-rate v_med3_f32 per lookup. Every x a call looks up is then one of the
+                                * sampler's draws (the weight p(x) / q(x); the independence sampler's proposals and initial
+                                * states), whose range the launch knows from the call's parameters; the kernel stages that many
+                                * more {outside, 0} sentinel cells either side of each table, so a lookup outside the table
+                                * still reads what the reference returns there (0 / -100: src/distribution.rs:190-195,
+                                * 384-389). A call whose range needs more than 4096 extra cells on a side is refused: ask
+                                * mcx_cell_pads before setting this. */
 } mcx_module_desc;
 
 #define MCX_RNG_PCG_REF 0
@@ -238,6 +246,10 @@ int  mcx_table_cell_map(const float* keys, uint32_t n, float* scale_out, float* 
 int  mcx_table_has_direct(const mcx_table* t);
 /* 1 if the table was stored with slope-intercept cells (PDF / log-PDF kinds on a strict f32-linspace grid), else 0. */
 int  mcx_table_has_cells(const mcx_table* t);
+/* 1 and the sentinel cells a cell_noclamp launch would add either side of table `t` when the call samples from
+ * (dist_type, param1, param2[, cdf]) -- 0 when the table has no cell form or the range is unbounded / too wide. */
+int  mcx_cell_pads(const mcx_table* t, int32_t dist_type, float param1, float param2, const mcx_table* cdf, int32_t guard_endpoints,
+                   uint32_t* pad_l, uint32_t* pad_r);
 int  mcx_table_cells(const float* keys, const float* values, uint32_t n, float* cells_out);
 
 /* ------------------------------------------------------------------------------------------

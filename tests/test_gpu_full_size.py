@@ -220,8 +220,13 @@ def test_bucket_direct_sampler_equals_the_guided_search(monkeypatch, rng):
         assert a.meta["n_eff"] == b.meta["n_eff"]
         # the ring puts different draws into one lane's pair / quad than the guided search does: the rounding of the
         # power-sum recurrences differs
-        tol = 3e-5 if key.startswith(("is12", "moments12")) else 3e-6
-        assert np.allclose(a.values, b.values, rtol=tol, atol=tol), (key, a.values, b.values)
+        if key.startswith(("is12", "moments12")):
+            # odd moments of a symmetric density cancel to ~0: the bound is relative to E|x|^k (the running maximum of the
+            # even moments stands in for it)
+            scale = np.maximum.accumulate(np.maximum(np.abs(b.values), 1.0))
+            assert np.all(np.abs(a.values - b.values) <= 3e-5 * scale), (key, a.values, b.values)
+        else:
+            assert np.allclose(a.values, b.values, rtol=3e-6, atol=3e-6), (key, a.values, b.values)
     assert np.allclose(direct["second"].meta["std_error"], guided["second"].meta["std_error"], rtol=1e-4)
     assert np.allclose(direct["second8"].meta["std_error"], guided["second8"].meta["std_error"], rtol=1e-4)
     assert abs(direct["general"].values[2] - 0.109375) < 1e-3          # P(Beta(2,5) > 0.5) = 7/64

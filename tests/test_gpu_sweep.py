@@ -195,3 +195,46 @@ def test_random_geometry_mcmc_extensions(case):
     total_steps = (ref["n_eff"] // n_steps) * (n_steps + n_burnin)
     assert abs(res.meta["accept_rate"] - ref["sums"][2] / total_steps) < 3e-3
     assert np.all(np.isfinite(res.meta["std_error"]))
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_random_geometry_moment_families(case):
+    """x, x**2, .., x**K for K from 8 to 32 on random small geometries, both streams, every sampler: power sums by Newton
+    pairs (below 12 rows on the reference stream) or by quads (the recurrence of the four samples' quartic), the CDF
+    sampler through its bucket-direct records with the append queue or the exchange ring -- against the f64 power sums
+    of the oracle's samples on the same stream, and as shards. Bound relative to sum |x|^k (sums of mixed sign cancel)."""
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo import runtime as rt
+    from wgpu_montecarlo.api import MonteCarloIntegrator, functions_to_hip
+
+    rng = np.random.default_rng(4000 + case)
+    k = int(rng.choice([8, 11, 12, 13, 16, 24, 32]))
+    philox = bool(rng.integers(0, 2))
+    target = int(rng.choice([256, 257, 700, 4096, 65536]))
+    n = int(rng.choice([5, 255, 1001, 4097, 99_999, 300_001, 1_000_003, 2_500_001]))
+    seed = int(rng.integers(0, 2**32))
+    kind = int(rng.integers(0, 4)) if case % 2 else 3           # every other case: the CDF sampler
+    beta = Distribution.beta(float(rng.uniform(1.5, 4)), float(rng.uniform(1.5, 6)), table_size=int(rng.choice([1000, 2048, 3000])))
+    dist, p1, p2, kw = [
+        (Distribution.uniform(-1.0, 1.25), -1.0, 1.25, {}),
+        (Distribution.normal(0.1, 0.4), 0.1, 0.4, {}),
+        (Distribution.exponential(4.0), 4.0, 0.0, {}),
+        (beta, 0.0, 0.0, dict(cdf_table=beta._cdf_table, x_table=beta._x_table)),
+    ][kind]
+    fns = [lambda x, p=p: x**p for p in range(1, k + 1)]
+    mc = MonteCarloIntegrator(target_threads=target, rng="philox" if philox else "pcg_ref")
+    res = mc.integrate(fns, dist, n_samples=n, seed=seed)
+    xs = oracle.samples(kind, p1, p2, n_samples=n, seed=seed, target_threads=target, guard=1, rng=int(philox), **kw)
+    assert res.meta["n_eff"] == xs.size
+    xs = xs.astype(np.float64).ravel()
+    want = np.array([(xs**p).sum() for p in range(1, k + 1)])
+    mag = np.array([(np.abs(xs) ** p).sum() for p in range(1, k + 1)])
+    got = res.values * xs.size
+    assert np.all(np.abs(got - want) <= 3e-5 * mag + 1e-30), (case, k, philox, kind, n, np.abs(got - want) / mag)
+    world = int(rng.choice([2, 3, 8]))
+    cdf = mc._cdf_table(dist)
+    desc = rt.make_desc(rt.KIND_INTEGRATE, k, kind, rng=rt.RNG_PHILOX if philox else rt.RNG_PCG_REF, moment_family=True,
+                        cdf_direct=cdf is not None and cdf.direct_bits > 0)
+    mod = mc._engine.module(functions_to_hip(fns), desc)
+    parts = [mc._engine.integrate(mod, n, seed, p1, p2, target, cdf=cdf, rank=r, world=world)[0] for r in range(world)]
+    assert np.all(np.abs(np.sum(parts, axis=0) - want) <= 3e-5 * mag + 1e-30), (case, world)

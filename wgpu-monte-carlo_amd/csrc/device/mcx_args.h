@@ -29,6 +29,7 @@ typedef struct McxTableDesc {
     float   cell_scale;
     mcx_u32 direct_bits;    // CDF tables: log2 of the number of bucket-direct records, 0 = none
     const float* direct;    // device pointer, 2 floats per bucket: {x_b, slope * 2^-32} or {lo | hi << 16, -0.0f}
+    mcx_u32 pad_l, pad_r;   // cell form, MCX_CELL_NOCLAMP launches: extra {outside, 0} sentinels staged either side (host: cell_pads)
 } McxTableDesc;
 
 // K1 / K2: plain and importance-sampling integration.

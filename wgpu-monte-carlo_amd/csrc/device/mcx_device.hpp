@@ -163,6 +163,8 @@ MCX_DEV void mcx_box_muller(u32 h1, u32 h2, float& z0, float& z1) {
     // -2 ln(f1 * 2^-32) = (32 - log2 f1) * 2 ln 2 >= 0. Only a 1-ulp overshoot of v_log_f32 at f1 ~ 2^32 could make it
     // -5e-6; |.| is an input modifier of v_sqrt_f32 (no instruction) and leaves every r2 >= 0 untouched.
     float l2 = __builtin_amdgcn_logf(f1);
+    // (Tried: the guard as the clamp modifier of an FMA forming (32 - log2 f1) / 33 in [0, 1] instead of the v_max_f32 on f1,
+    // one full-rate multiply more -- C2 0.396 against 0.394 ms, C3 0.667 / 0.660, C4 8.55 / 8.65: nothing in it.)
     float r2 = fmaf(l2, -0x1.62e43p+0f, 32.0f * 0x1.62e43p+0f);
     float r = __builtin_amdgcn_sqrtf(__builtin_fabsf(r2));
     z0 = r * __builtin_amdgcn_cosf(u2);
@@ -205,6 +207,8 @@ struct McxTable {
     const MCX_TBL float2* cells;  // PDF / log-PDF on a strict grid: cells[1 + c] = {intercept, slope} of cell c, cells[0] and
                           // cells[n] = {outside, 0} for x left / right of the table; else null (then kv is set)
     float cell_scale, cell_c0;   // padded cell index = floor(x * cell_scale + cell_c0) (host: cell_map)
+    float cell_s8, cell_c8;      // staged cells: LDS BYTE address of the cell = trunc(x * cell_s8 + cell_c8) & ~7
+    float cell_lo8, cell_hi8;    //   clamped to [lo8, hi8] = the two sentinels (not with MCX_CELL_NOCLAMP)
     const MCX_TBL float* slopes;  // CDF: slopes[c] = dx/dcdf of cell c (0 for cells narrower than 1e-10), or null
 };
 
@@ -382,12 +386,26 @@ MCX_COLD float mcx_table_lookup_cold(const MCX_TBL float2* kv, u32 n, float x, i
 // / 5.7e-6 max on C4's log-PDF table, the same as the reference's own f32 evaluation (2.7e-7 / 3.4e-6). Half the
 // LDS bytes and bank conflicts of the key/value form, ~10 VALU instead of ~24. Compiled in when the module was
 // built with cell_tables (every PDF / log-PDF table of the call has cells; the host layer decides per call).
+#ifndef MCX_CELL_NOCLAMP
+#define MCX_CELL_NOCLAMP 0
+#endif
 #if MCX_CELL_TABLES
 MCX_DEV float2 mcx_cell_fetch(const McxTable& tb, float x) {
-    // floor(x * scale + c0) clamped to [0, n] in one v_fma_f32 + one v_med3_f32: 0 and n are the {outside, 0}
-    // sentinels, so lanes outside the table need no compare / select afterwards; both table ends map inside.
+#if MCX_TABLES_LDS
+    // The cell's LDS byte address straight from the FMA: x * (8 scale) + (8 c0 + base), truncated, low three bits
+    // cleared -- v_fma, v_cvt_u32, v_and, against v_fma, v_cvt, v_lshl_add (half rate) for an index. The clamp to the
+    // two {outside, 0} sentinels is one v_med3_f32 (half rate; lanes outside the table need no compare / select
+    // afterwards, both table ends map inside); MCX_CELL_NOCLAMP launches stage sentinels over the sampler's whole
+    // range instead (host: cell_pads) and need none.
+    float t = fmaf(x, tb.cell_s8, tb.cell_c8);
+#if !MCX_CELL_NOCLAMP
+    t = __builtin_amdgcn_fmed3f(t, tb.cell_lo8, tb.cell_hi8);
+#endif
+    return *(const __attribute__((address_space(3))) float2*)((u32)t & ~7u);
+#else
     const float gf = __builtin_amdgcn_fmed3f(fmaf(x, tb.cell_scale, tb.cell_c0), 0.0f, (float)tb.n);
     return tb.cells[(u32)gf];
+#endif
 }
 #endif
 

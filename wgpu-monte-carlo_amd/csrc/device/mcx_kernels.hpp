@@ -120,6 +120,7 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
     t.slopes = nullptr;
     t.k0 = 0.0f;
     t.k1 = 0.0f;
+    t.cell_s8 = t.cell_c8 = t.cell_lo8 = t.cell_hi8 = 0.0f;
     if (d.n == 0u) return t;
 #if MCX_CELL_TABLES
     const bool cell_form = d.cells != nullptr;          // PDF / log-PDF table: stage the n-1 cells, not kv (CDF tables: kv)
@@ -129,10 +130,25 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
 #if MCX_TABLES_LDS
     MCX_TBL float2* dst = (MCX_TBL float2*)(mcx_lds_raw + off);
     const float2* src = (const float2*)(cell_form ? d.cells : d.kv);
-    const u32 count = cell_form ? d.n + 1u : d.n;       // cell form: two sentinels + n - 1 cells
-    for (u32 i = threadIdx.x; i < count; i += MCX_BLOCK) dst[i] = src[i];
-    off += count * 8u;
-    if (cell_form) t.cells = dst; else t.kv = dst;
+    if (cell_form) {
+        // two sentinels + n - 1 cells, and pad_l / pad_r more copies of the sentinels either side (MCX_CELL_NOCLAMP)
+        const u32 count = d.n + 1u + d.pad_l + d.pad_r;
+        for (u32 i = threadIdx.x; i < count; i += MCX_BLOCK) {
+            const u32 j = i < d.pad_l ? 0u : i - d.pad_l;
+            dst[i] = src[j < d.n ? j : d.n];
+        }
+        off += count * 8u;
+        t.cells = dst + d.pad_l;
+        const float base = (float)((u32)(__UINTPTR_TYPE__)dst + 8u * d.pad_l);          // byte address of sentinel 0: exact (< 2^24)
+        t.cell_s8 = mcx_in_vgpr(8.0f * d.cell_scale);
+        t.cell_c8 = mcx_in_vgpr(fmaf(8.0f, d.cell_c0, base));
+        t.cell_lo8 = mcx_in_vgpr(base);
+        t.cell_hi8 = mcx_in_vgpr(base + 8.0f * (float)d.n);
+    } else {
+        for (u32 i = threadIdx.x; i < d.n; i += MCX_BLOCK) dst[i] = src[i];
+        off += d.n * 8u;
+        t.kv = dst;
+    }
     if (d.slopes != nullptr) {
         MCX_TBL float* sdst = (MCX_TBL float*)(mcx_lds_raw + off);
         for (u32 i = threadIdx.x; i < d.n; i += MCX_BLOCK) sdst[i] = d.slopes[i];

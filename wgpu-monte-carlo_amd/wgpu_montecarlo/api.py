@@ -304,16 +304,39 @@ class MonteCarloIntegrator:
         return self._table(runtime.TABLE_CDF, dist._cdf_table, dist._x_table)
 
     @staticmethod
-    def _fit_tables(desc, *tables: Optional[runtime.Table]):
+    def _fit_tables(desc, *tables: Optional[runtime.Table], extra_bytes: int = 0):
         """Decide desc.tables_lds: do the staged forms of these tables fit next to the module's static LDS (its
         reduction scratch)? Same budget libmcx checks at launch (mcx_lds_table_budget). When they do not fit, the
         module is built with tables_lds = 0 and the same code reads the tables from HBM / L2."""
         need = sum(tb.lds_bytes for tb in tables if tb is not None)
+        budget = runtime.lds_table_budget(desc)
+        # the sentinel cells of cell_noclamp are only worth staging while they cost no occupancy: within the budget, and not
+        # across the half-CU line (two workgroups per CU) when the bare tables are below it
+        half = budget - runtime.LDS_PER_CU // 2
+        if desc.cell_noclamp and (need + extra_bytes > budget or need <= half < need + extra_bytes):
+            desc.cell_noclamp = 0
+        if desc.cell_noclamp:
+            need += extra_bytes
         desc.tables_lds = 1
-        if need > runtime.lds_table_budget(desc):
+        if need > budget:
             desc.tables_lds = 0
             desc.cdf_direct = 0            # the bucket-direct records only pay from LDS
+            desc.cell_noclamp = 0          # and so does the padded cell array
         return desc
+
+    def _cell_pads(self, cell_tables: bool, code: int, p1: float, p2: float, cdf, *tables) -> Optional[int]:
+        """desc.cell_noclamp: can every cell table of the call be padded over the sampler's range (then the lookup needs
+        no index clamp)? Returns the extra LDS bytes, or None when not (no cell tables, unbounded or too wide a range)."""
+        tables = [t for t in tables if t is not None]
+        if not cell_tables or not tables or os.environ.get("MCX_NO_NOCLAMP"):
+            return None
+        total = 0
+        for t in tables:
+            pads = runtime.cell_pads(t, code, p1, p2, cdf, self._guard)
+            if pads is None:
+                return None
+            total += 8 * sum(pads)
+        return total
 
     def _replicas(self, plan: "_Plan"):
         """[(engine, module, tables)] of a plan on every device of this integrator (built on first use)."""
@@ -440,14 +463,16 @@ class MonteCarloIntegrator:
         elif not q_sampler:
             user_src += "\n\n" + q_src
         k = len(functions)
+        cells = self._cell_tables(p_table, q_table)
+        pad_bytes = self._cell_pads(cells, code, p1, p2, cdf, p_table, q_table)
         desc = runtime.make_desc(runtime.KIND_INTEGRATE, k, code, weight=True,
                                  p_table=p_table is not None, q_table=q_table is not None,
                                  guard_endpoints=self._guard, precise_sampler=self._precise_sampler,
                                  rng=self._rng, second_moments=self._std_error,
                                  unit_params=_unit_params(code, p1, p2),
-                                 cell_tables=self._cell_tables(p_table, q_table), q_sampler=q_sampler,
+                                 cell_tables=cells, q_sampler=q_sampler, cell_noclamp=pad_bytes is not None,
                                  moment_family=self._use_moment_family(functions), cdf_direct=self._cdf_direct(cdf, k))
-        self._fit_tables(desc, cdf, p_table, q_table)
+        self._fit_tables(desc, cdf, p_table, q_table, extra_bytes=pad_bytes or 0)
         return _Plan("integrate", self._engine.module(user_src, desc), desc, k, runtime.result_rows(desc), p1, p2,
                      dict(cdf=cdf, target_pdf=p_table, proposal_pdf=q_table))
 
@@ -491,11 +516,14 @@ class MonteCarloIntegrator:
                     raise ValueError("adaptive_random_walk needs increments symmetric about 0: normal(0, s) or uniform(-w, w)")
                 walk = runtime.WALK_ADAPTIVE
         k = len(functions)
+        cells = self._cell_tables(t_table, q_table)
+        # independent proposals: every lookup is at a draw of the proposal, whose range is known -> no index clamp
+        pad_bytes = self._cell_pads(cells, code, p1, p2, cdf, t_table, q_table) if walk == runtime.WALK_INDEPENDENT else None
         desc = runtime.make_desc(runtime.KIND_MCMC, k, code, guard_endpoints=self._guard,
                                  precise_sampler=self._precise_sampler, rng=self._rng, block=block,
                                  unit_params=_unit_params(code, p1, p2), second_moments=self._std_error, walk=walk,
-                                 cell_tables=self._cell_tables(t_table, q_table), q_sampler=q_sampler)
-        self._fit_tables(desc, cdf, t_table, q_table)
+                                 cell_tables=cells, q_sampler=q_sampler, cell_noclamp=pad_bytes is not None)
+        self._fit_tables(desc, cdf, t_table, q_table, extra_bytes=pad_bytes or 0)
         return _Plan("mcmc", self._engine.module(user_src, desc), desc, k, runtime.result_rows(desc), p1, p2,
                      dict(cdf=cdf, target_logpdf=t_table, proposal_logpdf=q_table), x0=float(initial_state),
                      target_accept=float(target_accept), proposal_kind=proposal_kind, walk=walk)

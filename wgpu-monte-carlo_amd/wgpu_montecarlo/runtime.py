@@ -28,6 +28,7 @@ WALK_INDEPENDENT, WALK_RANDOM, WALK_RANDOM_SYMMETRIC, WALK_ADAPTIVE = 0, 1, 2, 3
 RNG_CODES = {"pcg_ref": RNG_PCG_REF, "philox": RNG_PHILOX}
 
 E_INVALID, E_RUNTIME, E_COMPILE, E_NODEVICE = -1, -2, -3, -4
+LDS_PER_CU = 160 * 1024          # gfx950 (csrc/mcx_runtime.cpp: kLdsPerCu)
 
 DIST_CODES = {"uniform": DIST_UNIFORM, "normal": DIST_NORMAL, "exponential": DIST_EXPONENTIAL, "custom": DIST_CUSTOM}
 
@@ -49,7 +50,7 @@ class ModuleDesc(C.Structure):
                 ("rng", C.c_int32), ("unit_params", C.c_int32), ("second_moments", C.c_int32),
                 ("walk", C.c_int32), ("cell_tables", C.c_int32), ("q_sampler", C.c_int32),
                 ("moment_family", C.c_int32), ("user_tables", C.c_int32), ("logpdf_analytic", C.c_int32),
-                ("cdf_direct", C.c_int32)]
+                ("cdf_direct", C.c_int32), ("cell_noclamp", C.c_int32)]
 
 
 class IntegrateParams(C.Structure):
@@ -76,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "mcx_mcmc", "mcx_mcmc_device", "mcx_integrate_multi", "mcx_mcmc_multi",
     "mcx_engine_last_launch_count", "mcx_module_static_lds", "mcx_lds_table_budget", "mcx_rccl_library",
     "mcx_comm_create", "mcx_comm_destroy", "mcx_comm_size", "mcx_integrate_comm", "mcx_mcmc_comm",
-    "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct", "mcx_mcmc_block_hint",
+    "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct", "mcx_mcmc_block_hint", "mcx_cell_pads",
 ]
 
 _lib = None
@@ -162,6 +163,7 @@ def load():
         L.mcx_table_cell_map.argtypes = [C.POINTER(C.c_float), u32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mcx_table_has_cells.argtypes = [vp]
         L.mcx_table_has_direct.argtypes = [vp]
+        L.mcx_cell_pads.argtypes = [vp, C.c_int32, C.c_float, C.c_float, vp, C.c_int32, C.POINTER(u32), C.POINTER(u32)]
         L.mcx_mcmc_block_hint.argtypes = [u32]
         L.mcx_mcmc_block_hint.restype = u32
         L.mcx_table_lds_bytes.argtypes = [vp]
@@ -252,13 +254,22 @@ def make_desc(kind: int, k: int, dist_type: int, weight: bool = False, p_table: 
               block: int = 0, tables_lds: bool = True, rng: int = 0, second_moments: bool = False,
               unit_params: bool = False, walk: int = 0, cell_tables: bool = False,
               q_sampler: bool = False, moment_family: bool = False, user_tables: int = 0,
-              logpdf_analytic: int = 0, cdf_direct: bool = False) -> ModuleDesc:
+              logpdf_analytic: int = 0, cdf_direct: bool = False, cell_noclamp: bool = False) -> ModuleDesc:
     if not block and os.environ.get("MCX_BLOCK"):        # tuning knob
         block = int(os.environ["MCX_BLOCK"])
     return ModuleDesc(kind, k, dist_type, int(weight), int(p_table), int(q_table), int(guard_endpoints),
                       int(precise_sampler), int(block), int(tables_lds), int(rng), int(unit_params), int(second_moments),
                       int(walk), int(cell_tables), int(q_sampler), int(moment_family), int(user_tables), int(logpdf_analytic),
-                      int(cdf_direct))
+                      int(cdf_direct), int(cell_noclamp))
+
+
+def cell_pads(table: "Table", dist_type: int, p1: float, p2: float, cdf: Optional["Table"] = None, guard: bool = True):
+    """(pad_l, pad_r): the sentinel cells a cell_noclamp launch adds either side of `table` when the call samples from
+    (dist_type, p1, p2[, cdf]); None when the table has no cell form or the sampler's range is unbounded / too wide."""
+    pl, pr = C.c_uint32(), C.c_uint32()
+    ok = load().mcx_cell_pads(table._h, int(dist_type), float(p1), float(p2), cdf._h if cdf is not None else None, int(guard),
+                              C.byref(pl), C.byref(pr))
+    return (pl.value, pr.value) if ok == 1 else None
 
 
 def table_cells(keys, values):
