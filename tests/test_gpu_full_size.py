@@ -44,6 +44,7 @@ def _wl(name):
 def test_c2_full_size(rng):
     wl = _wl("c2")
     res = wl.blocking(_mc(rng), 10**9, 42)
+    assert res.meta["block"] == 256           # no tables
     assert res.meta["n_eff"] == 65536 * 15259 == 1_000_013_824 and res.n_samples == 10**9
     truth, band = wl.band(res.meta["n_eff"])
     assert np.all(np.abs(res.values - truth) <= band), (res.values, truth, band)
@@ -55,6 +56,7 @@ def test_c3_full_size(rng):
     interpolant (what the lookup evaluates), band = 3 sigma of the importance-sampling estimator (both by quadrature)."""
     wl = _wl("c3")
     res = wl.blocking(_mc(rng), 10**9, 42)
+    assert res.meta["block"] == 512           # a 17 KiB PDF table
     assert res.meta["n_eff"] == 1_000_013_824
     truth, band = wl.band(res.meta["n_eff"])
     assert np.all(np.abs(res.values - truth) <= band), (res.values, truth, band)
@@ -68,6 +70,7 @@ def test_c4_full_size(rng, sigmas):
     independence sampler, E[x] = 0 and E[x^2] = 5 of the bimodal target within the batch-means band."""
     wl = _wl("c4")
     res = wl.blocking(_mc(rng), 1_048_576, 42)
+    assert res.meta["block"] == 512           # a 22 KiB log-PDF table: api._fit_tables
     assert res.meta["n_eff"] == 1_048_576 * 10_000 and res.n_samples == 1_048_576 * 10_000
     assert res.meta["n_blocks"] * res.meta["block"] == 1_048_576
     assert abs(res.meta["accept_rate"] - 0.6616) < 2e-3
@@ -85,6 +88,7 @@ def test_c5_full_size(rng, sigmas):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")                     # the reference stream warns beyond 2^32 samples
         res = wl.blocking(_mc(rng), 10**10, 42)
+    assert res.meta["block"] == 1024          # 72 KiB of CDF records: the large workgroup (two per CU)
     assert res.meta["n_eff"] == 65536 * 152588 == 10_000_007_168
     truth, band = wl.band(res.meta["n_eff"])
     assert np.all(np.abs(res.values - truth) <= sigmas * band), (np.abs(res.values - truth) / band)

@@ -49,7 +49,10 @@
 #define MCX_TABLES_LDS 1
 #endif
 #ifndef MCX_FLUSH
-#define MCX_FLUSH 128            // units accumulated in f32 before folding into the f64 sums
+// units accumulated in f32 before folding into the f64 sums. Many rows fold through the wave reduction + LDS
+// (MCX_WAVE_FLUSH), which costs ~8 instructions per row: half as often there (C5: 12.97 -> 12.75 ms; 64: 13.5 ms).
+// K = 4 is indifferent between 128 and 256 and loses below (C2: 0.393 / 0.393 / 0.403 / 0.409 ms at 256 / 128 / 64 / 32).
+#define MCX_FLUSH (MCX_K > 8 ? 256 : 128)
 #endif
 #ifndef MCX_UNROLL
 #define MCX_UNROLL 1             // unroll factor of the sampling loops (tuning knob)

@@ -322,6 +322,12 @@ class MonteCarloIntegrator:
             desc.tables_lds = 0
             desc.cdf_direct = 0            # the bucket-direct records only pay from LDS
             desc.cell_noclamp = 0          # and so does the padded cell array
+        elif (not desc.block and need > 0 and desc.dist_type != runtime.DIST_CUSTOM and 4 * need <= budget
+              and not os.environ.get("MCX_BLOCK")):
+            # libmcx's default for table kernels is 1024 threads (more waves share one staged copy -- what K = 32 on a
+            # 72 KiB CDF table needs). Small PDF / log-PDF tables, of which four copies fit a CU, run better with 512:
+            # C3 0.662 -> 0.629 ms, C4 8.65 -> 8.51 ms (256: 0.666 / 8.50; profiles/r02b_flush_period_and_block_size_sweep.txt)
+            desc.block = 512
         return desc
 
     def _cell_pads(self, cell_tables: bool, code: int, p1: float, p2: float, cdf, *tables) -> Optional[int]:
