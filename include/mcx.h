@@ -109,7 +109,7 @@ int  mcx_engine_last_launch(mcx_engine* e, uint32_t* n_blocks, uint32_t* block, 
 /* Main-kernel launches the last call was split into (1 unless the call exceeded the per-launch work bound of
  * ~1e11 samples / chain-steps, MCX_MAX_LAUNCH_UNITS; the reference always issues one dispatch, src/engine.rs:468-525). */
 uint32_t mcx_engine_last_launch_count(const mcx_engine* e);
-/* Tuning knob: physical threads a launch aims for (default 256 CUs x 2048 x 2). */
+/* Tuning knob: physical threads a launch aims for; 0 = the default, 4096 workgroups of the module's size (16 per CU). */
 int  mcx_engine_set_target_threads(mcx_engine* e, uint32_t physical_threads);
 
 /* ------------------------------------------------------------------------------------------

@@ -38,7 +38,7 @@ def test_random_geometry_k1(case):
     ][kind]
     mc = MonteCarloIntegrator(target_threads=target)
     mc._engine.set_target_threads(int(rng.choice([64, 4096, 100_000, 1 << 20, 1 << 22])))   # engines are shared:
-    request_default = lambda: mc._engine.set_target_threads(256 * 2048 * 2)                  # restored below
+    request_default = lambda: mc._engine.set_target_threads(0)                               # restored below
     try:
         res = mc.integrate(F, dist, n_samples=n, seed=seed)
     except Exception:
