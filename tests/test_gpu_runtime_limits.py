@@ -203,3 +203,24 @@ def test_process_exits_cleanly_whatever_the_import_order(mode):
     probe = Path(__file__).resolve().parent.parent / "tools" / "exit_order_probe.py"
     res = subprocess.run([sys.executable, str(probe), mode], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and f"done {mode}" in res.stdout, (res.returncode, res.stdout[-500:], res.stderr[-1500:])
+
+
+def test_launch_geometry_follows_the_work_per_workgroup(integrator):
+    """Workgroups per launch: 4096 (16 per CU) when every workgroup samples enough to pay for staging its tables into LDS
+    (6 samples per staged byte), never fewer than 1 Mi physical threads; table-less kernels always take 4096 workgroups of
+    256 once the call is large enough to be cut that far (profiles/r02b_launch_geometry_vs_call_size.txt)."""
+    from wgpu_montecarlo import Distribution
+
+    beta = Distribution.beta(2.0, 5.0)
+    f4 = [lambda x, p=p: x**p for p in range(1, 5)]
+    geometry = lambda res: (res.meta["n_blocks"], res.meta["block"])
+    assert geometry(integrator.integrate(f4, beta, n_samples=10**7)) == (1024, 1024)            # 72 KiB staged per workgroup
+    assert geometry(integrator.integrate(f4, beta, n_samples=3 * 10**9)) == (4096, 1024)
+    mid = geometry(integrator.integrate(f4, beta, n_samples=10**9))
+    assert mid[1] == 1024 and 1024 < mid[0] < 4096
+    assert geometry(integrator.integrate(f4, Distribution.normal(0.0, 1.0), n_samples=10**9)) == (4096, 256)
+    integrator._engine.set_target_threads(1 << 19)                # the override still rules
+    try:
+        assert geometry(integrator.integrate(f4, beta, n_samples=3 * 10**9)) == (512, 1024)
+    finally:
+        integrator._engine.set_target_threads(0)
