@@ -785,6 +785,8 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
 
 #endif          // MCX_KIND == 0
 
+template <int V> struct McxPhase { static constexpr int value = V; };
+
 // =============================================================================================
 // K3: Metropolis-Hastings, one chain per thread. MCX_WALK 0: independent proposals x' ~ q (the reference);
 // 1: random walk x' = x + d, d ~ q, with the Hastings correction log q(-d) - log q(d); 2: random walk with a
@@ -930,7 +932,12 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     float ad_log_s = 0.0f, ad_scale = 1.0f;      // per-chain step scale, adapted during burn-in only
     const float ad_target = mcx_in_vgpr(a.target_accept);
 #endif
-    auto mh_finish = [&](u32 it, float prop_x, float prop_lp, float prop_lq, float log_alpha, u32 ha) {
+    // `phase`: McxPhase<0> decides per step whether it is a sampling step and when to fold the f32 accumulators
+    // (wave-uniform compares and a counter: ~5 scalar instructions and 2 branches per step); <1> = a burn-in step,
+    // <2> = a sampling step inside a block whose caller folds -- the batched loop below knows which it is in.
+    u32 n_accept_blk = 0u;        // accepted steps of the current block (phases 1, 2): one 32-bit scalar add per step
+    auto mh_finish = [&](auto phase, u32 it, float prop_x, float prop_lp, float prop_lq, float log_alpha, u32 ha) {
+        constexpr int PHASE = decltype(phase)::value;
 #if MCX_PRECISE_SAMPLER
         float ln_u = logf(mcx_u01_closed(ha));
 #else
@@ -962,7 +969,8 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #else
         (void)prop_lq;
 #endif
-        n_accept += (u64)__builtin_popcountll(__builtin_amdgcn_ballot_w64(take));
+        if constexpr (PHASE == 0) n_accept += (u64)__builtin_popcountll(__builtin_amdgcn_ballot_w64(take));
+        else n_accept_blk += (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(take));
 #if MCX_WALK == 3
         if (it <= a.n_burnin) {                  // wave-uniform; diminishing adaptation, none while sampling
             // a chain that is still outside the target table rejects every proposal that does not land inside: that
@@ -972,12 +980,16 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
             ad_scale = __builtin_amdgcn_exp2f(ad_log_s * 1.4426950408889634f);
         }
 #endif
-        if (it > a.n_burnin) {                   // accumulate after every sampling step (shader_gen.rs:417-423)
+        if constexpr (PHASE == 2) {
             mcx_eval_all<1>(cur_x, 1.0f, acc);
-            if (++since_flush == 2u * MCX_FLUSH) {
+        } else if constexpr (PHASE == 0) {
+            if (it > a.n_burnin) {               // accumulate after every sampling step (shader_gen.rs:417-423)
+                mcx_eval_all<1>(cur_x, 1.0f, acc);
+                if (++since_flush == 2u * MCX_FLUSH) {
 #pragma unroll
-                for (int k = 0; k < MCX_K; ++k) { sum[k] += (double)acc[k]; acc[k] = 0.0f; }
-                since_flush = 0u;
+                    for (int k = 0; k < MCX_K; ++k) { sum[k] += (double)acc[k]; acc[k] = 0.0f; }
+                    since_flush = 0u;
+                }
             }
         }
     };
@@ -998,34 +1010,34 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #else
         const float prop_w = prop_lp - MCX_LOGQ(lq_tb, prop_x);
 #endif
-        mh_finish(it, prop_x, prop_w, 0.0f, prop_w - cur_lp, ha);
+        mh_finish(McxPhase<0>{}, it, prop_x, prop_w, 0.0f, prop_w - cur_lp, ha);
 #else
 #if MCX_Q_SAMPLER
         float prop_lq = -0.5f * zd * zd;
 #else
         float prop_lq = MCX_LOGQ(lq_tb, prop_x);
 #endif
-        mh_finish(it, prop_x, prop_lp, prop_lq, prop_lp + cur_lq - cur_lp - prop_lq, ha);   // shader_gen.rs:526
+        mh_finish(McxPhase<0>{}, it, prop_x, prop_lp, prop_lq, prop_lp + cur_lq - cur_lp - prop_lq, ha);   // shader_gen.rs:526
 #endif
 #elif MCX_WALK == 1
         const float prop_x = cur_x + draw;
         float prop_lp = MCX_LOGP(lp_tb, prop_x);
 #if MCX_Q_SAMPLER
         // d = m + s z: log q(-d) - log q(d) = (z^2 - (z + 2m/s)^2) / 2 = -(2m/s) (z + m/s)
-        mh_finish(it, prop_x, prop_lp, 0.0f, prop_lp - cur_lp - (2.0f * rw_ms) * (zd + rw_ms), ha);
+        mh_finish(McxPhase<0>{}, it, prop_x, prop_lp, 0.0f, prop_lp - cur_lp - (2.0f * rw_ms) * (zd + rw_ms), ha);
 #else
         float lq_fwd = MCX_LOGQ(lq_tb, draw);                     // q(x' | x) = q(d)
         float lq_back = MCX_LOGQ(lq_tb, -draw);                   // q(x | x') = q(-d)
-        mh_finish(it, prop_x, prop_lp, 0.0f, prop_lp + lq_back - cur_lp - lq_fwd, ha);
+        mh_finish(McxPhase<0>{}, it, prop_x, prop_lp, 0.0f, prop_lp + lq_back - cur_lp - lq_fwd, ha);
 #endif
 #elif MCX_WALK == 2
         const float prop_x = cur_x + draw;
         float prop_lp = MCX_LOGP(lp_tb, prop_x);
-        mh_finish(it, prop_x, prop_lp, 0.0f, prop_lp - cur_lp, ha);
+        mh_finish(McxPhase<0>{}, it, prop_x, prop_lp, 0.0f, prop_lp - cur_lp, ha);
 #else
         const float prop_x = fmaf(ad_scale, draw, cur_x);
         float prop_lp = MCX_LOGP(lp_tb, prop_x);
-        mh_finish(it, prop_x, prop_lp, 0.0f, prop_lp - cur_lp, ha);
+        mh_finish(McxPhase<0>{}, it, prop_x, prop_lp, 0.0f, prop_lp - cur_lp, ha);
 #endif
     };
 #if MCX_RNG == 0
@@ -1049,7 +1061,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #define MCX_MH_BATCH (MCX_W_STATE && MCX_DIST == MCX_DIST_NORMAL && MCX_RNG == 0)
 #endif
 #if MCX_MH_BATCH
-    auto mh_two_steps = [&](u32 it, float z0, float z1, u32 ha0, u32 ha1) {
+    auto mh_two_steps = [&](auto phase, u32 it, float z0, float z1, u32 ha0, u32 ha1) {
         const float x0 = MCX_AFFINE(z0), x1 = MCX_AFFINE(z1);
         const float lp0 = MCX_LOGP(lp_tb, x0), lp1 = MCX_LOGP(lp_tb, x1);
 #if MCX_Q_SAMPLER
@@ -1057,8 +1069,8 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #else
         const float w0 = lp0 - MCX_LOGQ(lq_tb, x0), w1 = lp1 - MCX_LOGQ(lq_tb, x1);
 #endif
-        mh_finish(it, x0, w0, 0.0f, w0 - cur_lp, ha0);
-        mh_finish(it + 1u, x1, w1, 0.0f, w1 - cur_lp, ha1);
+        mh_finish(phase, it, x0, w0, 0.0f, w0 - cur_lp, ha0);
+        mh_finish(phase, it + 1u, x1, w1, 0.0f, w1 - cur_lp, ha1);
     };
 #endif
 #if MCX_RNG == 1
@@ -1080,19 +1092,61 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     // new pair from counters 2*(it+OFFSET), +1 (distribution.rs:90-114 through shader_gen.rs:481)
     u32 it = 1u;
     if (total_steps >= 1u) { mh_step(1u, z_cached); it = 2u; }
+#if MCX_MH_BATCH
+    auto trip = [&](auto phase) {                 // steps it, it + 1
+        float z0, z1;
+        mcx_box_muller(mcx_pcg_out(st_prop), mcx_pcg_angle(st_prop + MCX_STATE_STEP), z0, z1);
+        st_prop += 4u * MCX_STATE_STEP;
+        const u32 ha0 = mcx_pcg_out(st_acc), ha1 = mcx_pcg_out(st_acc + MCX_STATE_STEP);
+        st_acc += 2u * MCX_STATE_STEP;
+        mh_two_steps(phase, it, z0, z1, ha0, ha1);
+        it += 2u;
+    };
+    // burn-in trips, at most one trip that straddles the end of the burn-in, then sampling trips in blocks of MCX_FLUSH
+    // (= 2 MCX_FLUSH steps, the cadence of the per-step counter) with the fold after each block: the step itself carries
+    // no phase test, no flush counter and a 32-bit accept count
+    // Measured on C4's kernel (ms per call, per-step tests / phased loops; profiles/r02b_mh_phased_loop_ab.txt):
+    // 1 048 576 chains 8.57 / 8.97, 524 288: 4.97 / 5.07, 262 144: 2.79 / 2.79, 131 072: 1.71 / 1.59, 65 536: 1.36 / 1.15.
+    // Fewer scalar instructions win where a shard leaves 2-4 waves per SIMD and each wave's own instruction stream is
+    // exposed; with 8 waves per SIMD the tighter loop is SLOWER -- the waves run it in step and meet at the transcendental
+    // unit and the LDS together, where the per-step scalar work of the other form keeps them apart. The host layer picks
+    // 256-thread workgroups exactly for those small shards (mcx_mcmc_block_hint), so the workgroup size selects the form.
+    // (Starting the waves of a SIMD 128 .. 6400 cycles apart does not substitute for it: phased 8.97 -> 8.86 ms, and it
+    // costs C2 and C3 6 %.)
+#ifndef MCX_MH_PHASED
+#define MCX_MH_PHASED (MCX_BLOCK <= 256)
+#endif
+#if !MCX_MH_PHASED
+    while (it + 1u <= total_steps) trip(McxPhase<0>{});
+#endif
+    while (it + 1u <= total_steps && it + 1u <= a.n_burnin) {
+        u32 blk_end = it + (1u << 20);            // the 32-bit accept count of a block cannot overflow
+        blk_end = blk_end < a.n_burnin ? blk_end : a.n_burnin;
+        blk_end = blk_end < total_steps ? blk_end : total_steps;
+        while (it + 1u <= blk_end) trip(McxPhase<1>{});
+        n_accept += (u64)n_accept_blk;
+        n_accept_blk = 0u;
+    }
+    if (it + 1u <= total_steps && it <= a.n_burnin) trip(McxPhase<0>{});
+    while (it + 1u <= total_steps) {
+        u32 blk_end = it + 2u * MCX_FLUSH - 1u - since_flush;         // last step of this block
+        blk_end = blk_end < total_steps ? blk_end : total_steps;
+        while (it + 1u <= blk_end) trip(McxPhase<2>{});
+        n_accept += (u64)n_accept_blk;
+        n_accept_blk = 0u;
+        since_flush = 0u;
+#pragma unroll
+        for (int k = 0; k < MCX_K; ++k) { sum[k] += (double)acc[k]; acc[k] = 0.0f; }
+    }
+#else
     for (; it + 1u <= total_steps; it += 2u) {
         float z0, z1;
         mcx_box_muller(mcx_pcg_out(st_prop), mcx_pcg_angle(st_prop + MCX_STATE_STEP), z0, z1);
         st_prop += 4u * MCX_STATE_STEP;
-#if MCX_MH_BATCH
-        const u32 ha0 = mcx_pcg_out(st_acc), ha1 = mcx_pcg_out(st_acc + MCX_STATE_STEP);
-        st_acc += 2u * MCX_STATE_STEP;
-        mh_two_steps(it, z0, z1, ha0, ha1);
-#else
         mh_step(it, z0);
         mh_step(it + 1u, z1);
-#endif
     }
+#endif
     if (it <= total_steps && it >= 2u) {
         float z0, z1;
         mcx_box_muller(mcx_pcg_out(st_prop), mcx_pcg_angle(st_prop + MCX_STATE_STEP), z0, z1);
