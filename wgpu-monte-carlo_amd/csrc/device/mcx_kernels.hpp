@@ -16,7 +16,7 @@
 //
 // Design differences (MI355X-first):
 //   * logical (idx, i) sample grid is decoupled from physical threads: each logical thread's loop
-//     is cut into chunks so that >= 16 waves/CU are resident whatever T is; the multiset of samples
+//     is cut into chunks so that up to 4096 workgroups (16 per CU) exist whatever T is; the multiset of samples
 //     is unchanged, only the summation order differs.
 //   * per-thread sums go f32 registers -> f64 registers every MCX_FLUSH units -> wave64 xor-shuffle
 //     -> LDS across waves -> one contiguous record `partials[workgroup][k]`; a second tiny kernel

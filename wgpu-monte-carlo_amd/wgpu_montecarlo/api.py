@@ -419,9 +419,10 @@ class MonteCarloIntegrator:
     def _cdf_direct(self, cdf: Optional[runtime.Table], k: int) -> bool:
         """Sample a custom distribution through the bucket-direct form of its CDF table (one read + one FMA for draws
         whose bucket holds no cdf node, the rest resolved in batches) when the table has one; math="precise" keeps the
-        reference's search + blend. Measured on Beta(2,5), 2e9 samples, warm device: 1.42 ms against 1.63 ms for the guided
-        search at K = 4, 1.92 / 2.05 ms at K = 16, 2.79 / 2.77 ms at K = 32 (the evaluation dominates there): used up to
-        16 rows (profiles/r02_cdf_sampler_warm_device_ab.jsonl)."""
+        reference's search + blend. Both streams. Measured on Beta(2,5), 2e9 samples, warm device, against the guided search:
+        1.40 / 1.65 ms at K = 4, 1.77 / 1.99 ms at K = 16, 2.48 / 2.62 ms at K = 32 on the reference stream (from 12 rows
+        the kernel's queue is an exchange ring, so that no lane sits the evaluation out), 1.60 / 1.88 and 2.70 / 2.85 ms at
+        K = 4 / 32 on Philox (profiles/r02b_moment_family_and_direct_sampler_ab.txt). Up to 32 accumulator rows."""
         rows = k * (2 if self._std_error else 1)
         return (cdf is not None and cdf.direct_bits > 0 and not self._precise_sampler
                 and rows <= int(os.environ.get("MCX_DIRECT_MAX_ROWS", "32")) and not os.environ.get("MCX_NO_DIRECT"))
