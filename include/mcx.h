@@ -190,6 +190,10 @@ typedef struct mcx_module_desc {
                                 * still reads what the reference returns there (0 / -100: src/distribution.rs:190-195,
                                 * 384-389). A call whose range needs more than 4096 extra cells on a side is refused: ask
                                 * mcx_cell_pads before setting this. */
+    int32_t cell_addr16;       /* 1 (with cell_tables and tables_lds): the caller guarantees that static + dynamic LDS of every launch stay
+                                * within 64 KiB, so a cell's LDS byte address fits 16 bits and is read straight out of the mantissa
+                                * of the index FMA (offset by 2^16: ulp 2^-7 byte) -- a shift and an AND instead of a half-rate
+                                * v_cvt_u32_f32. Checked at launch. */
 } mcx_module_desc;
 
 #define MCX_RNG_PCG_REF 0

@@ -389,6 +389,9 @@ MCX_COLD float mcx_table_lookup_cold(const MCX_TBL float2* kv, u32 n, float x, i
 #ifndef MCX_CELL_NOCLAMP
 #define MCX_CELL_NOCLAMP 0
 #endif
+#ifndef MCX_CELL_ADDR16
+#define MCX_CELL_ADDR16 0
+#endif
 #if MCX_CELL_TABLES
 MCX_DEV float2 mcx_cell_fetch(const McxTable& tb, float x) {
 #if MCX_TABLES_LDS
@@ -401,7 +404,13 @@ MCX_DEV float2 mcx_cell_fetch(const McxTable& tb, float x) {
 #if !MCX_CELL_NOCLAMP
     t = __builtin_amdgcn_fmed3f(t, tb.cell_lo8, tb.cell_hi8);
 #endif
+#if MCX_CELL_ADDR16
+    // the constants carry + 2^16 (mcx_stage_table): t lies in [2^16, 2^17), its mantissa is the byte address times 2^7 --
+    // a shift and an AND (full rate) instead of the half-rate v_cvt_u32_f32
+    return *(const __attribute__((address_space(3))) float2*)((__builtin_bit_cast(u32, t) >> 7) & 0xFFF8u);
+#else
     return *(const __attribute__((address_space(3))) float2*)((u32)t & ~7u);
+#endif
 #else
     const float gf = __builtin_amdgcn_fmed3f(fmaf(x, tb.cell_scale, tb.cell_c0), 0.0f, (float)tb.n);
     return tb.cells[(u32)gf];

@@ -142,7 +142,8 @@ MCX_DEV McxTable mcx_stage_table(const McxTableDesc& d, u32& off) {
         }
         off += count * 8u;
         t.cells = dst + d.pad_l;
-        const float base = (float)((u32)(__UINTPTR_TYPE__)dst + 8u * d.pad_l);          // byte address of sentinel 0: exact (< 2^24)
+        // byte address of sentinel 0: exact (< 2^24); MCX_CELL_ADDR16: + 2^16, the address is then read out of the mantissa
+        const float base = (float)((u32)(__UINTPTR_TYPE__)dst + 8u * d.pad_l + (MCX_CELL_ADDR16 ? 65536u : 0u));
         t.cell_s8 = mcx_in_vgpr(8.0f * d.cell_scale);
         t.cell_c8 = mcx_in_vgpr(fmaf(8.0f, d.cell_c0, base));
         t.cell_lo8 = mcx_in_vgpr(base);

@@ -318,6 +318,11 @@ class MonteCarloIntegrator:
         if desc.cell_noclamp:
             need += extra_bytes
         desc.tables_lds = 1
+        # everything within 64 KiB of LDS (static scratch included: LDS_PER_CU - budget): a cell's byte address fits 16 bits
+        # and comes out of the index FMA's mantissa. Measured: C4 8.60 -> 8.52 ms; C3 0.624 -> 0.632 ms (slower, although it
+        # trades a half-rate convert for a full-rate shift) -- MCMC modules only (profiles/r02b_cell_addr16_ab.txt)
+        desc.cell_addr16 = int(desc.kind == runtime.KIND_MCMC and bool(desc.cell_tables) and need > 0
+                               and need + (runtime.LDS_PER_CU - budget) <= 65536 and not os.environ.get("MCX_NO_ADDR16"))
         if need > budget:
             desc.tables_lds = 0
             desc.cdf_direct = 0            # the bucket-direct records only pay from LDS

@@ -50,7 +50,7 @@ class ModuleDesc(C.Structure):
                 ("rng", C.c_int32), ("unit_params", C.c_int32), ("second_moments", C.c_int32),
                 ("walk", C.c_int32), ("cell_tables", C.c_int32), ("q_sampler", C.c_int32),
                 ("moment_family", C.c_int32), ("user_tables", C.c_int32), ("logpdf_analytic", C.c_int32),
-                ("cdf_direct", C.c_int32), ("cell_noclamp", C.c_int32)]
+                ("cdf_direct", C.c_int32), ("cell_noclamp", C.c_int32), ("cell_addr16", C.c_int32)]
 
 
 class IntegrateParams(C.Structure):
@@ -254,13 +254,14 @@ def make_desc(kind: int, k: int, dist_type: int, weight: bool = False, p_table: 
               block: int = 0, tables_lds: bool = True, rng: int = 0, second_moments: bool = False,
               unit_params: bool = False, walk: int = 0, cell_tables: bool = False,
               q_sampler: bool = False, moment_family: bool = False, user_tables: int = 0,
-              logpdf_analytic: int = 0, cdf_direct: bool = False, cell_noclamp: bool = False) -> ModuleDesc:
+              logpdf_analytic: int = 0, cdf_direct: bool = False, cell_noclamp: bool = False,
+              cell_addr16: bool = False) -> ModuleDesc:
     if not block and os.environ.get("MCX_BLOCK"):        # tuning knob
         block = int(os.environ["MCX_BLOCK"])
     return ModuleDesc(kind, k, dist_type, int(weight), int(p_table), int(q_table), int(guard_endpoints),
                       int(precise_sampler), int(block), int(tables_lds), int(rng), int(unit_params), int(second_moments),
                       int(walk), int(cell_tables), int(q_sampler), int(moment_family), int(user_tables), int(logpdf_analytic),
-                      int(cdf_direct), int(cell_noclamp))
+                      int(cdf_direct), int(cell_noclamp), int(cell_addr16))
 
 
 def cell_pads(table: "Table", dist_type: int, p1: float, p2: float, cdf: Optional["Table"] = None, guard: bool = True):
