@@ -83,3 +83,39 @@ def test_too_wide_a_range_keeps_the_clamp(integrator):
     with pytest.raises(ValueError, match="cell_noclamp needs cell_tables"):
         eng.module(functions_to_hip(f2), rt.make_desc(rt.KIND_MCMC, 2, rt.DIST_NORMAL, cell_tables=True, cell_noclamp=True,
                                                       walk=rt.WALK_RANDOM_SYMMETRIC))
+
+
+def test_cell_address_from_the_mantissa(monkeypatch):
+    """desc.cell_addr16 (MCMC modules within 64 KiB of LDS): the cell's byte address is read out of the index FMA's
+    mantissa instead of converted. Same chains as with the convert (MCX_NO_ADDR16=1) up to the neighbour-cell rounding at
+    nodes; a launch that needs more than 64 KiB of LDS is refused."""
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+    from wgpu_montecarlo import runtime as rt
+    from wgpu_montecarlo.api import functions_to_hip
+
+    f2 = [lambda x: x, lambda x: x * x]
+    target = Distribution.from_pdf(_bump, support=(-4.0, 5.0))
+
+    def run(mc):
+        return [mc.integrate_mcmc(f2, target, q, n_steps=400, n_chains=4096, n_burnin=50, seed=5)
+                for q in (Distribution.normal(0.0, 3.0), Distribution.uniform(-5.0, 6.0), Distribution.normal(0.0, 40.0))]
+
+    fast = run(MonteCarloIntegrator())
+    monkeypatch.setenv("MCX_NO_ADDR16", "1")
+    plain = run(MonteCarloIntegrator())
+    for a, b in zip(fast, plain):
+        assert a.meta["n_eff"] == b.meta["n_eff"]
+        assert np.allclose(a.values, b.values, rtol=1e-6, atol=1e-9), (a.values, b.values)
+        assert abs(a.meta["accept_rate"] - b.meta["accept_rate"]) < 1e-6
+    monkeypatch.delenv("MCX_NO_ADDR16")
+
+    mc = MonteCarloIntegrator()
+    big = Distribution.from_pdf(_bump, support=(-4.0, 5.0), table_size=9000)           # 72 KiB of cells
+    tx, tl = big.get_log_pdf_table()
+    tb = mc._engine.cached_table(rt.TABLE_LOGPDF, tx, tl)
+    forced = rt.make_desc(rt.KIND_MCMC, 2, rt.DIST_NORMAL, cell_tables=True, q_sampler=True, cell_addr16=True)
+    mod = mc._engine.module(functions_to_hip(f2), forced)
+    with pytest.raises(ValueError, match="does not fit 16 bits"):
+        mc._engine.mcmc(mod, 50, 4096, 10, 3, 0.0, 3.0, tb, None)
+    res = mc.integrate_mcmc(f2, big, Distribution.normal(0.0, 3.0), n_steps=200, n_chains=4096, n_burnin=20, seed=5)   # the API does not set it
+    assert np.all(np.isfinite(res.values))
