@@ -1118,6 +1118,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #define MCX_MH_PHASED (MCX_BLOCK <= 256)
 #endif
 #if !MCX_MH_PHASED
+    // (Four proposals ahead of four accept tests instead of two: 8.79 against 8.54 ms. Not kept.)
     while (it + 1u <= total_steps) trip(McxPhase<0>{});
 #endif
     while (it + 1u <= total_steps && it + 1u <= a.n_burnin) {
