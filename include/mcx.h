@@ -254,6 +254,10 @@ int  mcx_table_has_cells(const mcx_table* t);
  * (dist_type, param1, param2[, cdf]) -- 0 when the table has no cell form or the range is unbounded / too wide. */
 int  mcx_cell_pads(const mcx_table* t, int32_t dist_type, float param1, float param2, const mcx_table* cdf, int32_t guard_endpoints,
                    uint32_t* pad_l, uint32_t* pad_r);
+/* The same from the table's keys alone, no GPU needed (the strict-grid index map of mcx_table_cell_map; for a custom
+ * sampling distribution pass the range of its CDF table's x column with have_x = 1). */
+int  mcx_cell_pads_host(const float* keys, uint32_t n, int32_t dist_type, float param1, float param2, int32_t have_x, float x_min,
+                        float x_max, int32_t guard_endpoints, uint32_t* pad_l, uint32_t* pad_r);
 int  mcx_table_cells(const float* keys, const float* values, uint32_t n, float* cells_out);
 
 /* ------------------------------------------------------------------------------------------

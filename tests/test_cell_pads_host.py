@@ -1,0 +1,78 @@
+"""desc.cell_noclamp on the host (no GPU): the sentinel cells the launch stages either side of a cell table must cover
+every index the device's unclamped lookup can form -- floor(fma(x, scale, c0 + pad_l)) in f32 -- for every x the sampler
+can produce (include/mcx.h: mcx_cell_pads_host; csrc/mcx_runtime.cpp: sampler_reach, cell_pads)."""
+import math
+
+import numpy as np
+import pytest
+
+from wgpu_montecarlo import runtime as rt
+
+F = np.float32
+
+
+def _extreme_draws(dist, p1, p2, x_range):
+    """The most extreme x each sampler can return, evaluated in f32 the way device/mcx_device.hpp does."""
+    if dist == rt.DIST_UNIFORM:
+        span = F(p2) - F(p1)
+        return [F(p1), F(F(1.0) * span + F(p1)), F(F(float.fromhex("0x1.fffffep-1")) * span + F(p1))]
+    if dist == rt.DIST_NORMAL:
+        # Box-Muller with f1 >= 0.5: r^2 = (32 - log2 f1) 2 ln 2 <= 33 * 2 ln 2; |cos|, |sin| <= 1 (+ 1 ulp of v_sin / v_cos)
+        r = F(math.sqrt(33.0 * 2.0 * math.log(2.0))) * F(1.0 + 2.0**-20)
+        return [F(F(p2) * z + F(p1)) for z in (r, -r)]
+    if dist == rt.DIST_EXPONENTIAL:
+        return [F(0.0), F(F(-math.log(1e-7)) * F(1.0 + 2.0**-20) / F(p1))]
+    return [F(x_range[0]), F(x_range[1])]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_pads_cover_every_index_the_unclamped_lookup_can_form(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([2, 3, 17, 300, 512, 1000, 2048, 4096]))
+    x0 = float(rng.uniform(-50, 50))
+    width = float(10 ** rng.uniform(-2, 2))
+    keys = np.linspace(x0, x0 + width, n).astype(np.float32)
+    scale, c0 = rt.table_cell_map(keys)
+    dist = int(rng.integers(0, 4))
+    p1, p2, x_range = 0.0, 1.0, None
+    if dist == rt.DIST_UNIFORM:
+        p1 = x0 + float(rng.uniform(-2, 1)) * width
+        p2 = p1 + float(rng.uniform(0.1, 3)) * width
+    elif dist == rt.DIST_NORMAL:
+        p1, p2 = x0 + float(rng.uniform(-1, 2)) * width, float(rng.uniform(0.01, 0.4)) * width
+    elif dist == rt.DIST_EXPONENTIAL:
+        p1 = float(rng.uniform(0.05, 20)) / width
+    else:
+        lo = x0 + float(rng.uniform(-2, 0.5)) * width
+        x_range = (lo, lo + float(rng.uniform(0.1, 3)) * width)
+    pads = rt.cell_pads_host(keys, dist, p1, p2, x_range)
+    if pads is None:                                   # too wide a range: the clamped module is built instead
+        cells_per_unit = (n - 1) / width
+        assert any(abs(float(x) - x0) * cells_per_unit > 3000 or abs(float(x) - x0 - width) * cells_per_unit > 3000
+                   for x in _extreme_draws(dist, p1, p2, x_range)), (seed, dist, p1, p2)
+        return
+    pad_l, pad_r = pads
+    assert 1 <= pad_l <= 4096 and 1 <= pad_r <= 4096
+    staged = n + 1 + pad_l + pad_r                     # sentinels + n - 1 cells + sentinels
+    c0p = F(c0 + F(pad_l))
+    for x in _extreme_draws(dist, p1, p2, x_range) + [F(keys[0]), F(keys[-1])]:
+        t = F(np.float64(x) * np.float64(scale) + np.float64(c0p))          # one rounding, like v_fma_f32
+        idx = int(math.floor(float(t)))
+        assert 0 <= idx < staged, (seed, dist, float(x), idx, staged, pads)
+    # in-table x still land on their own cell: pad_l + 1 + c
+    mid = F(0.5 * (float(keys[n // 2 - 1]) + float(keys[n // 2]))) if n > 2 else F(0.5 * (float(keys[0]) + float(keys[1])))
+    t = F(np.float64(mid) * np.float64(scale) + np.float64(c0p))
+    assert int(math.floor(float(t))) == pad_l + 1 + (n // 2 - 1 if n > 2 else 0)
+
+
+def test_unbounded_or_degenerate_ranges_are_refused():
+    keys = np.linspace(0.0, 1.0, 512).astype(np.float32)
+    assert rt.cell_pads_host(keys, rt.DIST_NORMAL, 0.5, 0.1) is not None
+    assert rt.cell_pads_host(keys, rt.DIST_NORMAL, 0.5, 0.1, guard=False) is None          # u1 = 0: infinite deviate
+    assert rt.cell_pads_host(keys, rt.DIST_NORMAL, 0.5, float("inf")) is None
+    assert rt.cell_pads_host(keys, rt.DIST_EXPONENTIAL, 0.0, 0.0) is None
+    assert rt.cell_pads_host(keys, rt.DIST_EXPONENTIAL, -2.0, 0.0) is None
+    assert rt.cell_pads_host(keys, rt.DIST_CUSTOM, 0.0, 0.0) is None                       # no CDF table range given
+    assert rt.cell_pads_host(keys, rt.DIST_CUSTOM, 0.0, 0.0, x_range=(-1.0, 2.0)) == (511, 511)   # 509.x cells each side (the index map is shrunk by 2 eps), floor + 1
+    assert rt.cell_pads_host(keys, rt.DIST_UNIFORM, 0.25, 0.75) == (1, 1)
+    assert rt.cell_pads_host(keys, rt.DIST_NORMAL, 0.5, 10.0) is None                      # 6.8 sigma = 34 000 cells
