@@ -111,6 +111,9 @@ int  mcx_engine_last_launch(mcx_engine* e, uint32_t* n_blocks, uint32_t* block, 
 uint32_t mcx_engine_last_launch_count(const mcx_engine* e);
 /* Tuning knob: physical threads a launch aims for; 0 = the default, 4096 workgroups of the module's size (16 per CU). */
 int  mcx_engine_set_target_threads(mcx_engine* e, uint32_t physical_threads);
+/* The default: workgroups a launch of `samples` samples aims for when each workgroup stages `lds_bytes` of tables --
+ * 4096 (16 per CU) once every workgroup samples at least 6 samples per staged byte, never fewer than 2^20 / block. */
+uint32_t mcx_default_launch_blocks(uint64_t samples, uint32_t lds_bytes, uint32_t block);
 
 /* ------------------------------------------------------------------------------------------
  * Modules -- replaces generate_*_shader (src/shader_gen.rs:45, 134, 312) +

@@ -76,3 +76,19 @@ def test_unbounded_or_degenerate_ranges_are_refused():
     assert rt.cell_pads_host(keys, rt.DIST_CUSTOM, 0.0, 0.0, x_range=(-1.0, 2.0)) == (511, 511)   # 509.x cells each side (the index map is shrunk by 2 eps), floor + 1
     assert rt.cell_pads_host(keys, rt.DIST_UNIFORM, 0.25, 0.75) == (1, 1)
     assert rt.cell_pads_host(keys, rt.DIST_NORMAL, 0.5, 10.0) is None                      # 6.8 sigma = 34 000 cells
+
+
+def test_default_launch_geometry():
+    """Workgroups per launch (mcx_default_launch_blocks): 4096 without staged tables; with tables one workgroup per
+    6 x lds_bytes samples, clamped to [2^20 / block, 4096] (profiles/r02b_launch_geometry_vs_call_size.txt)."""
+    f = rt.default_launch_blocks
+    assert f(10**9, 0, 256) == 4096 and f(10**3, 0, 256) == 4096            # the unit count caps it later (plan_integrate)
+    assert f(10**7, 73728, 1024) == 1024 and f(3 * 10**8, 73728, 1024) == 1024
+    assert f(10**9, 73728, 1024) == 10**9 // (6 * 73728) == 2260
+    assert f(3 * 10**9, 73728, 1024) == 4096 and f(10**10, 73728, 1024) == 4096
+    assert f(10**8, 17920, 512) == 2048 and f(10**9, 17920, 512) == 4096
+    assert f(10**9, 0, 64) == 16384                                          # small workgroups: never below 2^20 threads
+    assert f(10**9, 4096, 64) == 16384
+    assert f(10**9, 0, 0) == 0
+    blocks = [f(n, 73728, 1024) for n in (10**6, 10**7, 10**8, 10**9, 10**10, 10**11)]
+    assert blocks == sorted(blocks)

@@ -77,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "mcx_mcmc", "mcx_mcmc_device", "mcx_integrate_multi", "mcx_mcmc_multi",
     "mcx_engine_last_launch_count", "mcx_module_static_lds", "mcx_lds_table_budget", "mcx_rccl_library",
     "mcx_comm_create", "mcx_comm_destroy", "mcx_comm_size", "mcx_integrate_comm", "mcx_mcmc_comm",
-    "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct", "mcx_mcmc_block_hint", "mcx_cell_pads", "mcx_cell_pads_host",
+    "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct", "mcx_mcmc_block_hint", "mcx_cell_pads", "mcx_cell_pads_host", "mcx_default_launch_blocks",
 ]
 
 _lib = None
@@ -164,6 +164,8 @@ def load():
         L.mcx_table_has_cells.argtypes = [vp]
         L.mcx_table_has_direct.argtypes = [vp]
         L.mcx_cell_pads.argtypes = [vp, C.c_int32, C.c_float, C.c_float, vp, C.c_int32, C.POINTER(u32), C.POINTER(u32)]
+        L.mcx_default_launch_blocks.argtypes = [C.c_uint64, u32, u32]
+        L.mcx_default_launch_blocks.restype = u32
         L.mcx_cell_pads_host.argtypes = [C.POINTER(C.c_float), u32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_float,
                                          C.c_int32, C.POINTER(u32), C.POINTER(u32)]
         L.mcx_mcmc_block_hint.argtypes = [u32]
@@ -273,6 +275,11 @@ def cell_pads(table: "Table", dist_type: int, p1: float, p2: float, cdf: Optiona
     ok = load().mcx_cell_pads(table._h, int(dist_type), float(p1), float(p2), cdf._h if cdf is not None else None, int(guard),
                               C.byref(pl), C.byref(pr))
     return (pl.value, pr.value) if ok == 1 else None
+
+
+def default_launch_blocks(samples: int, lds_bytes: int, block: int) -> int:
+    """Workgroups a launch aims for by default (include/mcx.h: mcx_default_launch_blocks)."""
+    return int(load().mcx_default_launch_blocks(int(samples), int(lds_bytes), int(block)))
 
 
 def cell_pads_host(keys, dist_type: int, p1: float, p2: float, x_range=None, guard: bool = True):
