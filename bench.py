@@ -63,6 +63,10 @@ def parse_args(argv=None):
                          "the CUs the previous step's tail leaves idle (measured 0.420 -> 0.397 ms per step); the default "
                          "stays 1 so that a launch's duration in the rocprofv3 trace is the kernel alone, not two "
                          "launches sharing the chip")
+    ap.add_argument("--mcmc-segments", type=int, default=0,
+                    help="c4 only, opt-in: run each MCMC call as two chain halves on two streams x this many step segments "
+                         "(mcx_engine_set_mcmc_segments; measured 8.5 -> 8.0 ms at 8). Default 0: one launch per call, so "
+                         "that a traced launch is the whole call")
     ap.add_argument("--rng", default="pcg_ref", help="stream of the headline loop: pcg_ref (the reference's) or philox")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the measured configuration) or gloo (rehearsal)")
     ap.add_argument("--single-device", action="store_true",
@@ -355,6 +359,8 @@ def run_rank(args):
         mc = MonteCarloIntegrator(device=local_rank, rng=rng, process_group=group)
         if args.target_phys:
             mc._engine.set_target_threads(args.target_phys)
+        if args.mcmc_segments:
+            mc._engine.set_mcmc_segments(args.mcmc_segments)
         return mc, wl.prepare(mc)
 
     integ, prepared = make(args.rng)
@@ -467,7 +473,7 @@ def run_rank(args):
                 "parallelism": (f"{'chain' if args.config == 'c4' else 'sample-grid'} shards x{world}, one {backend} "
                                 f"sum all-reduce of {wl.rows} f64 per step") if world > 1 else "single GPU",
                 "accumulate": "f32 registers per <= 128 units -> f64",
-                "rng": args.rng, "streams": args.streams,
+                "rng": args.rng, "streams": args.streams, "mcmc_segments": args.mcmc_segments,
                 "hip_runtime": _rt.hip_runtime(),
             },
             "rccl_ranks": dist.get_world_size() if (world > 1 and args.backend == "nccl") else None,

@@ -111,6 +111,13 @@ int  mcx_engine_last_launch(mcx_engine* e, uint32_t* n_blocks, uint32_t* block, 
 uint32_t mcx_engine_last_launch_count(const mcx_engine* e);
 /* Tuning knob: physical threads a launch aims for; 0 = the default, 4096 workgroups of the module's size (16 per CU). */
 int  mcx_engine_set_target_threads(mcx_engine* e, uint32_t physical_threads);
+/* Opt-in (default 0 = one launch per call; MCX_MCMC_SEGMENTS sets the default): run an MCMC call of the batched
+ * independence sampler (normal proposal, reference stream, no precise_sampler / second_moments / walk) as two halves of
+ * the chains on two streams, each cut into `segments` launches over consecutive step ranges. A launch that fills the chip
+ * exactly twice -- 1 048 576 chains -- leaves CUs idle while its last workgroups finish; the other half's next segment
+ * covers that (C4: 8.5 -> 8.0 ms with 8 segments). Same chains, same draws: the streams are functions of (seed, chain,
+ * step), the chain state {x, w} travels through a device buffer, every launch adds its own partial sums. */
+int  mcx_engine_set_mcmc_segments(mcx_engine* e, uint32_t segments);
 /* The default: workgroups a launch of `samples` samples aims for when each workgroup stages `lds_bytes` of tables --
  * 4096 (16 per CU) once every workgroup samples at least 6 samples per staged byte, never fewer than 2^20 / block. */
 uint32_t mcx_default_launch_blocks(uint64_t samples, uint32_t lds_bytes, uint32_t block);

@@ -224,3 +224,49 @@ def test_launch_geometry_follows_the_work_per_workgroup(integrator):
         assert geometry(integrator.integrate(f4, beta, n_samples=3 * 10**9)) == (512, 1024)
     finally:
         integrator._engine.set_target_threads(0)
+
+
+@pytest.mark.parametrize("segments", [2, 5, 8])
+def test_mcmc_time_segments_run_the_same_chains(integrator, segments):
+    """Opt-in mcx_engine_set_mcmc_segments: two halves of the chains on two streams, each cut into step segments that
+    resume every chain from its saved {x, w}. The draws are functions of (seed, chain, step), so the chains are the SAME
+    chains: accepted-step count identical, sums equal up to the regrouping of the f32 accumulation blocks -- for odd and
+    even burn-in lengths, step counts that leave a single trailing step, chain counts that do not halve into whole
+    workgroups, and a launch on a caller's stream."""
+    import torch
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo import runtime as rt
+
+    target = Distribution.from_pdf(lambda x: 0.5 * (np.exp(-0.5 * (x - 2) ** 2) + np.exp(-0.5 * (x + 2) ** 2)), support=(-10, 10))
+    proposal = Distribution.normal(0.0, 2.0)
+    f2 = [lambda x: x, lambda x: x * x]
+    eng = integrator._engine
+    cases = [(2000, 4096, 300), (1999, 4096 + 256, 301), (64, 768, 7), (501, 65_536, 0), (37, 512, 100)]
+    plain = [integrator.integrate_mcmc(f2, target, proposal, n_steps=s, n_chains=c, n_burnin=b, seed=11) for s, c, b in cases]
+    assert all(eng.last_launch()["launches"] == 1 for _ in (0,))
+    eng.set_mcmc_segments(segments)
+    try:
+        cut = [integrator.integrate_mcmc(f2, target, proposal, n_steps=s, n_chains=c, n_burnin=b, seed=11) for s, c, b in cases]
+        launches = eng.last_launch()["launches"]
+        # the asynchronous form on a caller's stream
+        prep = integrator.prepare_mcmc(f2, target, proposal)
+        out = torch.zeros(prep.rows, dtype=torch.float64, device="cuda")
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            n_eff = prep.launch(2000, 4096, 300, 11, out)
+        side.synchronize()
+        # precise math / Philox / random walk are not the batched sampler: one launch, whatever the setting
+        other = integrator.integrate_mcmc(f2, target, proposal, n_steps=200, n_chains=1024, n_burnin=20, seed=3,
+                                          proposal_kind="random_walk")
+        assert eng.last_launch()["launches"] == 1 and np.all(np.isfinite(other.values))
+    finally:
+        eng.set_mcmc_segments(0)
+    assert launches == 2 * min(segments, (37 + 100) // 4) or launches == 2 * segments
+    for a, b, (s, c, bn) in zip(plain, cut, cases):
+        assert a.meta["n_eff"] == b.meta["n_eff"]
+        assert a.meta["accept_rate"] == b.meta["accept_rate"], (s, c, bn)          # the same accept decisions, all of them
+        assert np.allclose(a.values, b.values, rtol=2e-6, atol=2e-6), (s, c, bn, a.values, b.values)
+    assert n_eff == plain[0].meta["n_eff"]
+    assert np.allclose(out.cpu().numpy()[:2] / n_eff, plain[0].values, rtol=2e-6, atol=2e-6)
+    with pytest.raises(ValueError):
+        eng.set_mcmc_segments(65)

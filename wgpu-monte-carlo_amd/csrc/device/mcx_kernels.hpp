@@ -847,7 +847,8 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     const u32 g = blockIdx.x * MCX_BLOCK + threadIdx.x;
     const bool active = __builtin_amdgcn_readfirstlane(g) < a.chain_count;
     const u32 idx = a.chain_begin + (active ? g : 0u);
-    const u32 total_steps = active ? a.n_burnin + a.n_steps : 0u;     // wave-uniform
+    // the last step this launch runs (a time segment ends earlier: McxMcmcArgs.it_end); wave-uniform
+    const u32 total_steps = active ? (a.it_end ? a.it_end : a.n_burnin + a.n_steps) : 0u;
 
     double sum[MCX_MCMC_ROWS];
 #pragma unroll
@@ -1092,6 +1093,18 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     // odd `it` consumes the z1 cached by the previous draw (it = 1: the initial draw's), even `it` draws a
     // new pair from counters 2*(it+OFFSET), +1 (distribution.rs:90-114 through shader_gen.rs:481)
     u32 it = 1u;
+#if MCX_MH_BATCH
+    if (a.it_begin > 1u) {                        // a later time segment: resume (x, w); the streams follow from `it`
+        it = a.it_begin;                          // even (host: segments end on odd steps)
+        if (active) {
+            const float2 st = ((const float2*)a.seg_state)[g];
+            cur_x = st.x;
+            cur_lp = st.y;
+        }
+        st_prop = mcx_state(a.seed, idx, 2u * (it + MCX_PROP_ITER_OFFSET));
+        st_acc = mcx_state(a.seed + MCX_ACCEPT_SEED_OFFSET, idx, it);
+    } else
+#endif
     if (total_steps >= 1u) { mh_step(1u, z_cached); it = 2u; }
 #if MCX_MH_BATCH
     auto trip = [&](auto phase) {                 // steps it, it + 1
@@ -1154,6 +1167,14 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
         mcx_box_muller(mcx_pcg_out(st_prop), mcx_pcg_angle(st_prop + MCX_STATE_STEP), z0, z1);
         mh_step(it, z0);
     }
+#if MCX_MH_BATCH
+    if (a.seg_state != nullptr && active) {
+        float2 st;
+        st.x = cur_x;
+        st.y = cur_lp;
+        ((float2*)a.seg_state)[g] = st;
+    }
+#endif
 #else
     for (u32 it = 1u; it <= total_steps; ++it) {
         u32 h = mcx_pcg_out(st_prop);

@@ -77,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "mcx_mcmc", "mcx_mcmc_device", "mcx_integrate_multi", "mcx_mcmc_multi",
     "mcx_engine_last_launch_count", "mcx_module_static_lds", "mcx_lds_table_budget", "mcx_rccl_library",
     "mcx_comm_create", "mcx_comm_destroy", "mcx_comm_size", "mcx_integrate_comm", "mcx_mcmc_comm",
-    "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct", "mcx_mcmc_block_hint", "mcx_cell_pads", "mcx_cell_pads_host", "mcx_default_launch_blocks",
+    "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct", "mcx_mcmc_block_hint", "mcx_cell_pads", "mcx_cell_pads_host", "mcx_default_launch_blocks", "mcx_engine_set_mcmc_segments",
 ]
 
 _lib = None
@@ -148,6 +148,7 @@ def load():
         L.mcx_engine_last_kernel_ms.restype = C.c_float
         L.mcx_engine_last_launch.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
         L.mcx_engine_set_target_threads.argtypes = [vp, u32]
+        L.mcx_engine_set_mcmc_segments.argtypes = [vp, u32]
         L.mcx_module_build.argtypes = [vp, C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(vp)]
         L.mcx_module_precompile.argtypes = [C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(C.c_int)]
         L.mcx_result_rows.argtypes = [C.POINTER(ModuleDesc)]
@@ -516,6 +517,11 @@ class Engine:
         res["u"] = u[:n]
         res["philox"] = po[:len(pc)]
         return res
+
+    def set_mcmc_segments(self, n: int) -> None:
+        """Opt-in: MCMC calls of the batched independence sampler as two chain halves on two streams x n step segments
+        (include/mcx.h: mcx_engine_set_mcmc_segments); 0 = one launch per call."""
+        check(load().mcx_engine_set_mcmc_segments(self._h, int(n)))
 
     def set_target_threads(self, n: int) -> None:
         check(load().mcx_engine_set_target_threads(self._h, int(n)))
