@@ -46,7 +46,7 @@ def main():
     calls = 0
     first = None
     while time.time() - t0 < args.seconds:
-        kind = int(rng.integers(0, 9))
+        kind = int(rng.integers(0, 11))
         mc = MonteCarloIntegrator(target_threads=int(rng.choice([256, 4096, 65536])), rng=str(rng.choice(["pcg_ref", "philox"])),
                                   std_error=bool(rng.integers(0, 2)))
         fns = make_fn(float(rng.integers(1, 40)) / 8.0)[: int(rng.integers(1, 5))]
@@ -94,6 +94,33 @@ def main():
             assert np.allclose(r.values, one.values, rtol=1e-8, atol=1e-8), (r.values, one.values)
             for eng in multi._engines[1:]:
                 eng.close()
+        elif kind == 9:
+            # an MCMC call cut into time segments on two streams against the same call in one launch: the same chains
+            plain = MonteCarloIntegrator()
+            tgt = Distribution.from_pdf(lambda x: math.exp(-0.5 * (x - 0.7) ** 2), support=(-6.0, 6.0), table_size=int(rng.choice([700, 2048])))
+            kw = dict(n_steps=int(rng.choice([8, 61, 400, 1501])), n_chains=int(rng.choice([256, 1000, 8192, 70_000])),
+                      n_burnin=int(rng.choice([0, 1, 20, 333])), seed=calls)
+            one = plain.integrate_mcmc(fns[:2], tgt, Distribution.normal(0.2, 1.7), **kw)
+            plain._engine.set_mcmc_segments(int(rng.choice([2, 3, 8])))
+            try:
+                r = plain.integrate_mcmc(fns[:2], tgt, Distribution.normal(0.2, 1.7), **kw)
+            finally:
+                plain._engine.set_mcmc_segments(0)
+            assert r.meta["accept_rate"] == one.meta["accept_rate"], (kw, r.meta["accept_rate"], one.meta["accept_rate"])
+            assert np.allclose(r.values, one.values, rtol=5e-6, atol=5e-6), (kw, r.values, one.values)
+        elif kind == 10:
+            # importance sampling / MH with padded, unclamped cell tables against the clamped lookup
+            xs = np.linspace(-3.0, 4.0, int(rng.choice([200, 512, 1500])))
+            tab = Distribution.from_pdf_table(xs, np.exp(-0.5 * (xs - 0.5) ** 2))
+            prop = [Distribution.normal(0.3, 2.0), Distribution.uniform(-5.0, 6.0), Distribution.exponential(0.5)][int(rng.integers(0, 3))]
+            r = mc.integrate_importance_sampling(fns, tab, prop, n_samples=n, seed=calls)
+            os.environ["MCX_NO_NOCLAMP"] = "1"
+            try:
+                g = MonteCarloIntegrator(target_threads=mc._target_threads, rng="pcg_ref" if mc._rng == 0 else "philox",
+                                         std_error=mc._std_error).integrate_importance_sampling(fns, tab, prop, n_samples=n, seed=calls)
+            finally:
+                del os.environ["MCX_NO_NOCLAMP"]
+            assert np.allclose(r.values, g.values, rtol=5e-6, atol=5e-6), (r.values, g.values)
         else:
             lap = Distribution.from_pdf(lambda x: math.exp(-abs(x)) / 2, support=(-12.0, 12.0), table_size=int(rng.choice([512, 2048])))
             r = mc.integrate_importance_sampling(fns, Distribution.normal(0.0, 1.0), lap, n_samples=n, seed=calls)
