@@ -47,6 +47,21 @@ const char* mcx_version(void);
 const char* mcx_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
+ * ABI versioning. What this header replaces -- _core.MonteCarloIntegrator.integrate / integrate_is_tables /
+ * integrate_mcmc, src/lib.rs:47-59, 158-180, 296-324 -- is a stable positional signature; the structs below carry the
+ * same arguments by name and have grown from round to round. They only ever grow AT THE END, and each starts with
+ * `struct_size` = sizeof(the struct) as the CALLER compiled it (set by the mcx_*_init helpers below):
+ *   - a caller built against an older, shorter layout is accepted; the fields it does not know read as 0 (every
+ *     field added after the first release has 0 = "off / reference behaviour" as its default);
+ *   - a caller built against a newer, longer layout than this library is refused with MCX_E_INVALID;
+ *   - struct_size = 0 (a struct that was never initialised) is refused with MCX_E_INVALID.
+ * MCX_ABI_VERSION counts layouts: 1 = round 1 (module desc up to `unit_params`), 2 = round 2 (up to `cell_addr16`,
+ * unversioned), 3 = this one (struct_size first).
+ * ------------------------------------------------------------------------------------------ */
+#define MCX_ABI_VERSION 3
+uint32_t mcx_abi_version(void);        /* MCX_ABI_VERSION the library was built with */
+
+/* ------------------------------------------------------------------------------------------
  * Planning -- pure host arithmetic, usable without a GPU.
  * ------------------------------------------------------------------------------------------ */
 
@@ -111,12 +126,19 @@ int  mcx_engine_last_launch(mcx_engine* e, uint32_t* n_blocks, uint32_t* block, 
 uint32_t mcx_engine_last_launch_count(const mcx_engine* e);
 /* Tuning knob: physical threads a launch aims for; 0 = the default, 4096 workgroups of the module's size (16 per CU). */
 int  mcx_engine_set_target_threads(mcx_engine* e, uint32_t physical_threads);
-/* Opt-in (default 0 = one launch per call; MCX_MCMC_SEGMENTS sets the default): run an MCMC call of the batched
- * independence sampler (normal proposal, reference stream, no precise_sampler / second_moments / walk) as two halves of
- * the chains on two streams, each cut into `segments` launches over consecutive step ranges. A launch that fills the chip
- * exactly twice -- 1 048 576 chains -- leaves CUs idle while its last workgroups finish; the other half's next segment
- * covers that (C4: 8.5 -> 8.0 ms with 8 segments). Same chains, same draws: the streams are functions of (seed, chain,
- * step), the chain state {x, w} travels through a device buffer, every launch adds its own partial sums. */
+/* Time segments of an MCMC call of the batched independence sampler (normal proposal, reference stream, no
+ * precise_sampler / second_moments / walk): the call runs as two halves of the chains on two streams, each cut into
+ * `segments` launches over consecutive step ranges. A launch that fills the chip a small whole number of times --
+ * 1 048 576 chains = exactly twice -- leaves CUs idle while its last workgroups finish; the other half's next segment
+ * covers that (C4: 8.5 -> 8.0 ms with 8 segments). Same chains, same draws, same accept decisions: the streams are
+ * functions of (seed, chain, step), the chain state {x, w} travels through a device buffer, every launch adds its own
+ * partial sums (the reference issues one dispatch, src/engine.rs:468-525).
+ *   MCX_SEGMENTS_AUTO (the default; MCX_MCMC_SEGMENTS overrides it): 8 segments for launches of >= 1 048 576 chains
+ *   (two or more rounds of the chip's wave slots), one launch otherwise; 0 or 1: always one launch; 2..64: that many
+ *   whenever the call qualifies.
+ * The side stream, its events and the state buffer are kept PER CALLER STREAM (like the per-workgroup partial sums), so
+ * segmented calls in flight on different streams of one engine do not share them. */
+#define MCX_SEGMENTS_AUTO 0xFFFFFFFFu
 int  mcx_engine_set_mcmc_segments(mcx_engine* e, uint32_t segments);
 /* The default: workgroups a launch of `samples` samples aims for when each workgroup stages `lds_bytes` of tables --
  * 4096 (16 per CU) once every workgroup samples at least 6 samples per staged byte, never fewer than 2^20 / block. */
@@ -132,6 +154,7 @@ uint32_t mcx_default_launch_blocks(uint64_t samples, uint32_t lds_bytes, uint32_
 #define MCX_KIND_MCMC      1   /* K3 */
 
 typedef struct mcx_module_desc {
+    uint32_t struct_size;      /* sizeof(mcx_module_desc) in the caller's build: mcx_module_desc_init() */
     int32_t kind;              /* MCX_KIND_* */
     int32_t k;                 /* number of fused user functions user_func_0 .. user_func_{k-1} */
     int32_t dist_type;         /* sampling (K1/K2) or proposal (K3) distribution */
@@ -205,6 +228,14 @@ typedef struct mcx_module_desc {
                                 * of the index FMA (offset by 2^16: ulp 2^-7 byte) -- a shift and an AND instead of a half-rate
                                 * v_cvt_u32_f32. Checked at launch. */
 } mcx_module_desc;
+/* Zero-fill, set struct_size, and the two defaults that are not 0: guard_endpoints = 1, tables_lds = 1. */
+static inline void mcx_module_desc_init(mcx_module_desc* d) {
+    uint32_t i;
+    for (i = 0; i < sizeof(*d); ++i) ((unsigned char*)d)[i] = 0;
+    d->struct_size = (uint32_t)sizeof(*d);
+    d->guard_endpoints = 1;
+    d->tables_lds = 1;
+}
 
 #define MCX_RNG_PCG_REF 0
 #define MCX_RNG_PHILOX  1
@@ -222,6 +253,9 @@ int  mcx_result_rows(const mcx_module_desc* desc);
 int  mcx_module_build(mcx_engine* e, const char* user_src, const mcx_module_desc* desc, mcx_module** out);
 /* hiprtc compile into the on-disk cache only: needs no GPU. cache_hit may be NULL. */
 int  mcx_module_precompile(const char* user_src, const mcx_module_desc* desc, int* cache_hit);
+/* Cache key of the code object (user_src, desc) compiles to: 32 hex digits + NUL into key_out[33]. The code object is
+ * <mcx_cache_dir()>/<key>.hsaco; profiles/ identifies disassembled modules by it. Needs no GPU. */
+int  mcx_module_key(const char* user_src, const mcx_module_desc* desc, char* key_out);
 /* Full translation unit that would be compiled (for inspection / offline hipcc). Caller frees with mcx_free. */
 int  mcx_module_source(const char* user_src, const mcx_module_desc* desc, char** out_text);
 void mcx_free(void* p);
@@ -244,11 +278,6 @@ int  mcx_table_create(mcx_engine* e, int kind, const float* keys, const float* v
 void mcx_table_release(mcx_table* t);
 /* Host-side analysis results (also usable in tests): uniform-grid flag and guide-table bits. */
 int  mcx_table_info(const mcx_table* t, uint32_t* n, float* inv_dk, uint32_t* guide_bits);
-/* Host-side, no GPU needed: the per-cell line coefficients a PDF / log-PDF table on a strict f32-linspace grid is
- * stored with (value(x) = slope * x + intercept on cell c: the interpolant of src/distribution.rs:181-223 / 375-417 in
- * slope-intercept form, coefficients from f64). Returns 1 and fills cells_out[2 * (n - 1)] = {intercept, slope} per
- * cell (cells_out may be NULL), or 0 when the keys are not such a grid -- lookups then run the verified / searched
- * key-value path. */
 /* LDS bytes a launch stages for this table (key/value pairs or cells, CDF slopes, guide): what a module built with
  * tables_lds = 1 needs per workgroup for it. */
 uint32_t mcx_table_lds_bytes(const mcx_table* t);
@@ -265,16 +294,41 @@ int  mcx_table_has_cells(const mcx_table* t);
 int  mcx_cell_pads(const mcx_table* t, int32_t dist_type, float param1, float param2, const mcx_table* cdf, int32_t guard_endpoints,
                    uint32_t* pad_l, uint32_t* pad_r);
 /* The same from the table's keys alone, no GPU needed (the strict-grid index map of mcx_table_cell_map; for a custom
- * sampling distribution pass the range of its CDF table's x column with have_x = 1). */
+ * sampling distribution pass the range of its CDF table's x column with have_x = 1 -- only when that table's
+ * mcx_table_facts.reach_known is 1). */
 int  mcx_cell_pads_host(const float* keys, uint32_t n, int32_t dist_type, float param1, float param2, int32_t have_x, float x_min,
                         float x_max, int32_t guard_endpoints, uint32_t* pad_l, uint32_t* pad_r);
+/* Host-side, no GPU needed: the per-cell line coefficients a PDF / log-PDF table on a strict f32-linspace grid is
+ * stored with (value(x) = slope * x + intercept on cell c: the interpolant of src/distribution.rs:181-223 / 375-417 in
+ * slope-intercept form, coefficients from f64). Returns 1 and fills cells_out[2 * (n - 1)] = {intercept, slope} per
+ * cell (cells_out may be NULL), or 0 when the keys are not such a grid -- lookups then run the verified / searched
+ * key-value path. */
 int  mcx_table_cells(const float* keys, const float* values, uint32_t n, float* cells_out);
+/* Host-side, no GPU needed: everything mcx_table_create derives from a table before it uploads it -- what a planner
+ * needs to choose a module desc (tables_lds, cell_tables, cdf_direct, cell_noclamp) without a device. */
+typedef struct mcx_table_facts {
+    uint32_t struct_size;      /* sizeof(mcx_table_facts) in the caller's build */
+    uint32_t n;
+    uint32_t has_cells;        /* mcx_table_has_cells */
+    uint32_t direct_bits;      /* mcx_table_has_direct */
+    uint32_t guide_bits;       /* 0: no guide table (non-monotone keys or n > 4096) */
+    uint32_t lds_bytes;        /* mcx_table_lds_bytes */
+    float    inv_dk;           /* uniform-grid scale of the keys, 0 if they are not a uniform grid */
+    float    value_min, value_max;
+    uint32_t reach_known;      /* CDF tables: 1 if every draw stays within [value_min, value_max] -- the table has a guide
+                                * or bucket-direct form (monotone, n <= 4096: the search ends in the right cell) and
+                                * cdf[n-1] >= 1 (no u beyond the last node, where the cell's line is extrapolated) */
+} mcx_table_facts;
+int  mcx_table_analyse(int kind, const float* keys, const float* values, uint32_t n, mcx_table_facts* out);
+int  mcx_table_facts_of(const mcx_table* t, mcx_table_facts* out);       /* the same of a resident table */
 
 /* ------------------------------------------------------------------------------------------
  * Integration -- replaces _core.MonteCarloIntegrator.integrate (src/lib.rs:47-141) and
  * .integrate_is_tables (src/lib.rs:158-275): setup -> execute -> reduce.
  * ------------------------------------------------------------------------------------------ */
 typedef struct mcx_integrate_params {
+    uint32_t struct_size;        /* sizeof(mcx_integrate_params) in the caller's build: mcx_integrate_params_init() */
+    uint32_t reserved0;          /* 0 */
     uint64_t n_samples;          /* requested; rounded UP to T*L like the reference */
     int64_t  target_threads;     /* <= 0: default 65536 */
     uint32_t seed;
@@ -284,6 +338,12 @@ typedef struct mcx_integrate_params {
     const mcx_table* target_pdf;   /* MCX_TABLE_PDF when desc.p_table */
     const mcx_table* proposal_pdf; /* MCX_TABLE_PDF when desc.q_table */
 } mcx_integrate_params;
+static inline void mcx_integrate_params_init(mcx_integrate_params* p) {      /* zero-fill, struct_size, world = 1 */
+    uint32_t i;
+    for (i = 0; i < sizeof(*p); ++i) ((unsigned char*)p)[i] = 0;
+    p->struct_size = (uint32_t)sizeof(*p);
+    p->world = 1;
+}
 
 /* sums_out[k] = sum over this rank's shard of f_k(x) (*p/q); n_eff_out = T*L of the WHOLE grid.
  * The reference's return value is sums / n_eff (mean of per-thread means of equal length). */
@@ -301,6 +361,7 @@ int mcx_integrate_device(mcx_engine* e, mcx_module* m, const mcx_integrate_param
  * MCMC -- replaces _core.MonteCarloIntegrator.integrate_mcmc (src/lib.rs:296-431).
  * ------------------------------------------------------------------------------------------ */
 typedef struct mcx_mcmc_params {
+    uint32_t struct_size;        /* sizeof(mcx_mcmc_params) in the caller's build: mcx_mcmc_params_init() */
     uint32_t n_steps, n_chains, n_burnin;
     int64_t  target_threads;     /* > 0 overrides n_chains (src/engine.rs:860) */
     uint32_t seed;
@@ -312,6 +373,13 @@ typedef struct mcx_mcmc_params {
     float    x0;                 /* random-walk modules: chains start at x0 + d_0 (d_0 = the iter-0 draw); else ignored */
     float    target_accept;      /* MCX_WALK_ADAPTIVE: acceptance rate the step scale is tuned towards (0 < a < 1) */
 } mcx_mcmc_params;
+static inline void mcx_mcmc_params_init(mcx_mcmc_params* p) {                /* zero-fill, struct_size, world = 1 */
+    uint32_t i;
+    for (i = 0; i < sizeof(*p); ++i) ((unsigned char*)p)[i] = 0;
+    p->struct_size = (uint32_t)sizeof(*p);
+    p->world = 1;
+    p->target_accept = 0.44f;
+}
 
 /* sums_out[0..k) = sum over this rank's chains and all sampling steps of f_k(x_t);
  * sums_out[k] = number of accepted steps (burn-in included); n_eff_out = padded chains * n_steps.

@@ -6,6 +6,10 @@
  *
  * Prints "OK ..." lines; exits non-zero on any mismatch. Without a GPU it stops after the planning checks
  * with exit code 3.
+ *
+ * -DMCX_CLIENT_OLD_LAYOUT builds the same client as a caller compiled against an OLDER mcx.h would look to the
+ * library: its module desc ends with `unit_params` (the first release of the struct) and says so in struct_size.
+ * libmcx must zero-fill what such a caller does not know and give the same sums (include/mcx.h, "ABI versioning").
  */
 #include <dlfcn.h>
 #include <math.h>
@@ -13,6 +17,19 @@
 #include <string.h>
 
 #include "mcx.h"
+
+#ifdef MCX_CLIENT_OLD_LAYOUT
+typedef struct client_module_desc {            /* mcx_module_desc as of its first release */
+    uint32_t struct_size;
+    int32_t kind, k, dist_type, weight, p_table, q_table, guard_endpoints, precise_sampler, block, tables_lds, rng, unit_params;
+} client_module_desc;
+#define DESC_PTR(d) ((const mcx_module_desc*)(d))
+static void client_desc_init(client_module_desc* d) { memset(d, 0, sizeof *d); d->struct_size = (uint32_t)sizeof *d; d->guard_endpoints = 1; d->tables_lds = 1; }
+#else
+typedef mcx_module_desc client_module_desc;
+#define DESC_PTR(d) (d)
+static void client_desc_init(client_module_desc* d) { mcx_module_desc_init(d); }
+#endif
 
 #define LOAD(name) __typeof__(name)* p_##name = (__typeof__(name)*)dlsym(lib, #name); if (!p_##name) { fprintf(stderr, "missing %s\n", #name); return 2; }
 
@@ -30,6 +47,7 @@ int main(int argc, char** argv) {
     LOAD(mcx_module_build) LOAD(mcx_module_release) LOAD(mcx_integrate) LOAD(mcx_engine_last_kernel_ms)
     LOAD(mcx_hip_runtime) LOAD(mcx_comm_create) LOAD(mcx_comm_destroy) LOAD(mcx_comm_size) LOAD(mcx_integrate_comm)
     LOAD(mcx_rccl_library) LOAD(mcx_lds_table_budget) LOAD(mcx_module_static_lds) LOAD(mcx_engine_last_launch_count)
+    LOAD(mcx_abi_version) LOAD(mcx_result_rows)
 
     printf("OK version %s\n", p_mcx_version());
     mcx_dispatch d;
@@ -41,18 +59,32 @@ int main(int argc, char** argv) {
     if (s0.unit_begin != 0u || s0.unit_end != s1.unit_begin || s1.unit_end != 8u) return 1;
     printf("OK planning T=%u L=%u\n", d.total_threads, d.loops_per_thread);
 
+    /* versioned structs: the caller's layout is accepted, an uninitialised or a longer one is refused */
+    if (p_mcx_abi_version() != MCX_ABI_VERSION) { fprintf(stderr, "abi version %u\n", p_mcx_abi_version()); return 1; }
+    client_module_desc desc;
+    client_desc_init(&desc);
+    desc.kind = MCX_KIND_INTEGRATE; desc.k = 3; desc.dist_type = MCX_DIST_NORMAL;
+    if (p_mcx_result_rows(DESC_PTR(&desc)) != 3) { fprintf(stderr, "result_rows: %s\n", p_mcx_last_error()); return 1; }
+    {
+        struct { mcx_module_desc d; int32_t from_the_future[4]; } longer;
+        memset(&longer, 0, sizeof longer);
+        memcpy(&longer.d, &desc, sizeof desc);
+        longer.d.struct_size = (uint32_t)sizeof longer;
+        if (p_mcx_result_rows(&longer.d) != MCX_E_INVALID || !strstr(p_mcx_last_error(), "newer mcx.h")) return 1;
+        longer.d.struct_size = 0u;
+        if (p_mcx_result_rows(&longer.d) != MCX_E_INVALID || !strstr(p_mcx_last_error(), "struct_size is 0")) return 1;
+    }
+    printf("OK abi version %u, desc of %u bytes (library: %u)\n", p_mcx_abi_version(), (unsigned)sizeof desc, (unsigned)sizeof(mcx_module_desc));
+
     if (p_mcx_device_count() < 1) { printf("no GPU visible: stopping after the planning checks\n"); return 3; }
     mcx_engine* e = NULL;
     if (p_mcx_engine_create(0, &e)) { fprintf(stderr, "engine: %s\n", p_mcx_last_error()); return 1; }
     printf("OK engine on %s\n", p_mcx_hip_runtime());
-    mcx_module_desc desc;
-    memset(&desc, 0, sizeof desc);
-    desc.kind = MCX_KIND_INTEGRATE; desc.k = 3; desc.dist_type = MCX_DIST_NORMAL; desc.guard_endpoints = 1; desc.tables_lds = 1;
     mcx_module* m = NULL;
-    if (p_mcx_module_build(e, USER_SRC, &desc, &m)) { fprintf(stderr, "module: %s\n", p_mcx_last_error()); return 1; }
+    if (p_mcx_module_build(e, USER_SRC, DESC_PTR(&desc), &m)) { fprintf(stderr, "module: %s\n", p_mcx_last_error()); return 1; }
     mcx_integrate_params p;
-    memset(&p, 0, sizeof p);
-    p.n_samples = 100000000ull; p.seed = 42u; p.param1 = 0.0f; p.param2 = 1.0f; p.world = 1u;
+    mcx_integrate_params_init(&p);
+    p.n_samples = 100000000ull; p.seed = 42u; p.param1 = 0.0f; p.param2 = 1.0f;
     double sums[3]; uint64_t n_eff = 0;
     if (p_mcx_integrate(e, m, &p, sums, &n_eff)) { fprintf(stderr, "integrate: %s\n", p_mcx_last_error()); return 1; }
     double mean = sums[0] / (double)n_eff, second = sums[1] / (double)n_eff, tail = sums[2] / (double)n_eff;
@@ -61,7 +93,14 @@ int main(int argc, char** argv) {
     if (n_eff != 65536ull * 1526ull) return 1;
     if (fabs(mean) > 5e-4 || fabs(second - 1.0) > 1e-3 || fabs(tail - 0.158655) > 3e-4) return 1;
     if (p_mcx_engine_last_launch_count(e) != 1u) return 1;
-    if (p_mcx_lds_table_budget(&desc) + p_mcx_module_static_lds(m) > 160u * 1024u || p_mcx_lds_table_budget(&desc) < 150u * 1024u) return 1;
+    {   /* an uninitialised parameter block is refused, not read */
+        mcx_integrate_params raw;
+        memset(&raw, 0, sizeof raw);
+        raw.n_samples = 1000u; raw.world = 1u;
+        double junk[3]; uint64_t jn = 0;
+        if (p_mcx_integrate(e, m, &raw, junk, &jn) != MCX_E_INVALID || !strstr(p_mcx_last_error(), "struct_size is 0")) return 1;
+    }
+    if (p_mcx_lds_table_budget(DESC_PTR(&desc)) + p_mcx_module_static_lds(m) > 160u * 1024u || p_mcx_lds_table_budget(DESC_PTR(&desc)) < 150u * 1024u) return 1;
     /* single-process RCCL path: a communicator over this process's engines (here: the one GPU of the box); the call
      * ends with ncclAllReduce(K doubles) on the engine's stream instead of a host-side sum */
     {
@@ -81,7 +120,7 @@ int main(int argc, char** argv) {
     }
     desc.k = 0;                                                     /* src/lib.rs:61-65 */
     mcx_module* bad = NULL;
-    if (p_mcx_module_build(e, USER_SRC, &desc, &bad) != MCX_E_INVALID || !strstr(p_mcx_last_error(), "At least one function")) return 1;
+    if (p_mcx_module_build(e, USER_SRC, DESC_PTR(&desc), &bad) != MCX_E_INVALID || !strstr(p_mcx_last_error(), "At least one function")) return 1;
     printf("OK errors: %s\n", p_mcx_last_error());
     p_mcx_module_release(m);
     p_mcx_engine_destroy(e);

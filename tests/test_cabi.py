@@ -16,7 +16,9 @@ HEADER = (ROOT / "include" / "mcx.h").read_text()
 
 def declared_symbols():
     names = set(re.findall(r"\b(mcx_[a-z0-9_]+)\s*\(", HEADER))
-    return sorted(names)
+    inline = set(re.findall(r"static inline \w+ (mcx_[a-z0-9_]+)\s*\(", HEADER))      # the mcx_*_init helpers live in the header
+    assert inline == {"mcx_module_desc_init", "mcx_integrate_params_init", "mcx_mcmc_params_init"}
+    return sorted(names - inline)
 
 
 def test_library_loads_and_exports_every_declared_symbol():
@@ -230,3 +232,47 @@ def test_mcmc_block_hint_keeps_every_cu_busy():
     1 / 2 / 4 / 8 GPUs: 1 048 576 / 524 288 / 262 144 / 131 072 chains) so that 256 CUs get >= 4 workgroups each."""
     assert [rt.mcmc_block_hint(c) for c in (1_048_576, 524_288, 262_144, 131_072, 65_536, 256, 0)] == [1024, 512, 256, 256, 256, 256, 256]
     assert rt.mcmc_block_hint(2**31) == 1024
+
+
+def test_versioned_structs_accept_older_layouts_and_refuse_newer_ones():
+    """include/mcx.h "ABI versioning": struct_size first; shorter = an older caller (missing fields read as 0), longer =
+    a caller built against a newer header (refused), 0 = never initialised (refused)."""
+    lib = rt.load()
+    assert int(lib.mcx_abi_version()) == rt.ABI_VERSION == 3
+    desc = rt.make_desc(rt.KIND_MCMC, 2, rt.DIST_NORMAL, second_moments=True, walk=rt.WALK_ADAPTIVE)
+    assert desc.struct_size == C.sizeof(rt.ModuleDesc)
+    assert rt.result_rows(desc) == 3 * 2 + 1 + 1
+
+    class FirstRelease(C.Structure):               # the desc up to `unit_params`
+        _fields_ = rt.ModuleDesc._fields_[:13]
+    old = FirstRelease(C.sizeof(FirstRelease), rt.KIND_MCMC, 2, rt.DIST_NORMAL)
+    old.guard_endpoints, old.tables_lds = 1, 1
+    rows = lib.mcx_result_rows(C.cast(C.byref(old), C.POINTER(rt.ModuleDesc)))
+    assert rows == 3                                # second_moments / walk are not in that layout: they read as 0
+
+    class Newer(C.Structure):
+        _fields_ = rt.ModuleDesc._fields_ + [("from_the_future", C.c_int32 * 3)]
+    new = Newer()
+    C.memmove(C.byref(new), C.byref(desc), C.sizeof(rt.ModuleDesc))
+    new.struct_size = C.sizeof(Newer)
+    assert lib.mcx_result_rows(C.cast(C.byref(new), C.POINTER(rt.ModuleDesc))) == rt.E_INVALID
+    assert "newer mcx.h" in rt.last_error()
+    desc.struct_size = 0
+    with pytest.raises(ValueError, match="struct_size is 0"):
+        rt.result_rows(desc)
+    desc.struct_size = 8                            # smaller than the first release
+    with pytest.raises(ValueError, match="smaller than the first release"):
+        rt.result_rows(desc)
+
+
+def test_module_key_names_the_cached_code_object():
+    """mcx_module_key: the 32-hex-digit name of the code object in the cache directory (what profiles/ cites)."""
+    from wgpu_montecarlo.api import functions_to_hip
+
+    src = functions_to_hip([lambda x: x * 3.25])
+    desc = rt.make_desc(rt.KIND_INTEGRATE, 1, rt.DIST_UNIFORM)
+    key = rt.module_key(src, desc)
+    assert re.fullmatch(r"[0-9a-f]{32}", key)
+    rt.precompile(src, desc)
+    assert (Path(rt.cache_dir()) / f"{key}.hsaco").exists()
+    assert rt.module_key(src, rt.make_desc(rt.KIND_INTEGRATE, 1, rt.DIST_NORMAL)) != key

@@ -92,3 +92,60 @@ def test_default_launch_geometry():
     assert f(10**9, 0, 0) == 0
     blocks = [f(n, 73728, 1024) for n in (10**6, 10**7, 10**8, 10**9, 10**10, 10**11)]
     assert blocks == sorted(blocks)
+
+
+def test_custom_sampler_reach_is_known_only_when_draws_stay_inside_the_x_column():
+    """cell_noclamp took the reach of a custom sampling distribution as [min x, max x] of its CDF table. That
+    holds only if the search ends in the cell that holds u (guide / bucket-direct form: monotone, n <= 4096 -- the
+    reference's 12-step capped search, src/distribution.rs:128-158, can stop short beyond that) and no u lies beyond
+    the last node (cdf[n-1] >= 1), else the last cell's line is extrapolated. mcx_table_facts.reach_known says which."""
+    x = np.linspace(0.0, 1.0, 2048).astype(np.float32)
+    cdf = (x.astype(np.float64) ** 2).astype(np.float32)
+    cdf[-1] = 1.0
+    assert rt.table_facts(rt.TABLE_CDF, cdf, x).reach_known == 1
+    short = (cdf * np.float32(0.98)).astype(np.float32)           # monotone, but u in (0.98, 1] extrapolates the last cell
+    f = rt.table_facts(rt.TABLE_CDF, short, x)
+    assert f.reach_known == 0 and f.guide_bits > 0
+    # n > 4096: no guide, no bucket-direct records -> the capped search itself runs on the device
+    xb = np.linspace(0.0, 1.0, 8192).astype(np.float32)
+    cb = (xb.astype(np.float64) ** 2).astype(np.float32)
+    cb[-1] = 1.0
+    f = rt.table_facts(rt.TABLE_CDF, cb, xb)
+    assert f.guide_bits == 0 and f.direct_bits == 0 and f.reach_known == 0
+    # the capped search does stop short there: emulate distribution.rs:128-147 on the 8192-point table
+    lo, hi, u = 0, 8191, np.float32(0.999)
+    for _ in range(12):
+        if lo >= hi:
+            break
+        mid = (lo + hi) // 2
+        if cb[mid] < u:
+            lo = mid + 1
+        else:
+            hi = mid
+    true_lb = int(np.searchsorted(cb, u, side="left"))
+    assert lo != true_lb                                          # not the cell that holds u
+    # non-monotone cdf: no guide either
+    bad = cdf.copy()
+    bad[100] = bad[99] - np.float32(1e-3)
+    assert rt.table_facts(rt.TABLE_CDF, bad, x).reach_known == 0
+
+
+def test_table_facts_match_what_the_planner_needs():
+    """mcx_table_analyse (no GPU): the figures api._fit_tables decides with -- C3's 512-point PDF table, C4's 2048-point
+    log-PDF table, Beta(2,5)'s 2048-point CDF table."""
+    from wgpu_montecarlo import Distribution
+
+    xs = np.linspace(0, 10, 512)
+    t = Distribution.from_pdf_table(xs, np.exp(-xs))
+    f = rt.table_facts(rt.TABLE_PDF, *t.get_or_compute_pdf_table())
+    assert (f.n, f.has_cells, f.direct_bits, f.lds_bytes) == (512, 1, 0, 513 * 8) and f.inv_dk > 0
+    beta = Distribution.beta(2.0, 5.0)
+    f = rt.table_facts(rt.TABLE_CDF, beta._cdf_table, beta._x_table)
+    assert (f.n, f.has_cells, f.direct_bits, f.reach_known) == (2048, 0, 13, 1)
+    assert f.lds_bytes == 8192 * 8                                 # the bucket-direct records are the larger staged form
+    assert f.value_min == pytest.approx(float(beta._x_table.min())) and f.value_max == pytest.approx(float(beta._x_table.max()))
+    ragged = np.array([0.0, 0.1, 0.5, 0.6, 2.0], dtype=np.float32)
+    f = rt.table_facts(rt.TABLE_LOGPDF, ragged, -ragged)
+    assert f.has_cells == 0 and f.inv_dk == 0.0 and f.lds_bytes == 5 * 8
+    with pytest.raises(ValueError, match="at least 2 points"):
+        rt.table_facts(rt.TABLE_PDF, [0.0], [1.0])

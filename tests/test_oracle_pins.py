@@ -173,3 +173,21 @@ def test_philox_stream_statistics():
     assert np.all(np.abs(r["sums"] / r["n_eff"] - [0, 1, 0, 3]) < 4 * sigma)
     r = oracle.integrate(MOM[:2], oracle.UNIFORM, 0.0, 1.0, n_samples=10**7, seed=1, rng=1, guard=1)
     assert abs(r["sums"][0] / r["n_eff"] - 0.5) < 4e-4 and abs(r["sums"][1] / r["n_eff"] - 1 / 3) < 4e-4
+
+
+def test_numpy_restatement_agrees_with_the_c_oracle_on_the_same_stream():
+    """oracle/numpy_port.py was written independently of mcx_oracle.c from the same reference lines
+    (src/distribution.rs:62-114, src/shader_gen.rs:93-117): same counters, same f32 terms -> the f64 sums agree to the
+    rounding of libm vs numpy transcendentals. Even L, odd L (the discarded second half), a general N(mean, std)."""
+    from oracle import numpy_port as npp
+
+    pows = lambda k: [(oracle.FN_IDENTITY, 0)] + [(oracle.FN_POW, j) for j in range(2, k + 1)]
+    for n, seed, mean, std, k in [(1_000_000, 42, 0.0, 1.0, 4), (65536 * 5, 7, 0.0, 1.0, 2), (300_000, 99, 2.0, 3.0, 3)]:
+        sums, n_eff = npp.normal_moments(k, n, seed=seed, mean=mean, std=std)
+        ref = oracle.integrate(pows(k), oracle.NORMAL, mean, std, n_samples=n, seed=seed, guard=1)
+        assert n_eff == ref["n_eff"]
+        scale = np.array([abs(mean) + std] * k) ** np.arange(1, k + 1) * n_eff
+        assert np.all(np.abs(sums - ref["sums"]) <= 2e-6 * scale), (sums, ref["sums"])
+    # integer side: App. A.2 hash vectors through the numpy hash
+    for v in (0, 1, 42, 0xFFFFFFFF, 123456789):
+        assert int(npp.pcg_hash(np.uint32(v))[0]) == oracle.pcg_hash(v)

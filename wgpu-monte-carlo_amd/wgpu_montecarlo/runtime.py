@@ -44,7 +44,7 @@ class Shard(C.Structure):
 
 
 class ModuleDesc(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("dist_type", C.c_int32), ("weight", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("kind", C.c_int32), ("k", C.c_int32), ("dist_type", C.c_int32), ("weight", C.c_int32),
                 ("p_table", C.c_int32), ("q_table", C.c_int32), ("guard_endpoints", C.c_int32),
                 ("precise_sampler", C.c_int32), ("block", C.c_int32), ("tables_lds", C.c_int32),
                 ("rng", C.c_int32), ("unit_params", C.c_int32), ("second_moments", C.c_int32),
@@ -54,18 +54,28 @@ class ModuleDesc(C.Structure):
 
 
 class IntegrateParams(C.Structure):
-    _fields_ = [("n_samples", C.c_uint64), ("target_threads", C.c_int64), ("seed", C.c_uint32),
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32), ("n_samples", C.c_uint64), ("target_threads", C.c_int64), ("seed", C.c_uint32),
                 ("param1", C.c_float), ("param2", C.c_float), ("rank", C.c_uint32), ("world", C.c_uint32),
                 ("cdf", C.c_void_p), ("target_pdf", C.c_void_p), ("proposal_pdf", C.c_void_p)]
 
 
 class McmcParams(C.Structure):
-    _fields_ = [("n_steps", C.c_uint32), ("n_chains", C.c_uint32), ("n_burnin", C.c_uint32),
+    _fields_ = [("struct_size", C.c_uint32), ("n_steps", C.c_uint32), ("n_chains", C.c_uint32), ("n_burnin", C.c_uint32),
                 ("target_threads", C.c_int64), ("seed", C.c_uint32), ("param1", C.c_float),
                 ("param2", C.c_float), ("rank", C.c_uint32), ("world", C.c_uint32),
                 ("cdf", C.c_void_p), ("target_logpdf", C.c_void_p), ("proposal_logpdf", C.c_void_p),
                 ("x0", C.c_float), ("target_accept", C.c_float)]
 
+
+class TableFacts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n", C.c_uint32), ("has_cells", C.c_uint32), ("direct_bits", C.c_uint32),
+                ("guide_bits", C.c_uint32), ("lds_bytes", C.c_uint32), ("inv_dk", C.c_float), ("value_min", C.c_float),
+                ("value_max", C.c_float), ("reach_known", C.c_uint32)]
+
+
+_SZ_INTEGRATE, _SZ_MCMC = C.sizeof(IntegrateParams), C.sizeof(McmcParams)
+SEGMENTS_AUTO = 0xFFFFFFFF
+ABI_VERSION = 3
 
 # every symbol include/mcx.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
@@ -78,6 +88,7 @@ EXPORTED_SYMBOLS = [
     "mcx_engine_last_launch_count", "mcx_module_static_lds", "mcx_lds_table_budget", "mcx_rccl_library",
     "mcx_comm_create", "mcx_comm_destroy", "mcx_comm_size", "mcx_integrate_comm", "mcx_mcmc_comm",
     "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct", "mcx_mcmc_block_hint", "mcx_cell_pads", "mcx_cell_pads_host", "mcx_default_launch_blocks", "mcx_engine_set_mcmc_segments",
+    "mcx_abi_version", "mcx_module_key", "mcx_table_analyse", "mcx_table_facts_of",
 ]
 
 _lib = None
@@ -200,6 +211,12 @@ def load():
         L.mcx_selftest_streams.argtypes = [vp, u32, u32p, u32p, u32p, u32p, u32p, C.POINTER(C.c_float), u32, u32p, u32p, u32p]
         L.mcx_set_max_launch_units.argtypes = [u64]
         L.mcx_set_max_launch_units.restype = None
+        L.mcx_abi_version.restype = u32
+        L.mcx_module_key.argtypes = [C.c_char_p, C.POINTER(ModuleDesc), C.c_char_p]
+        L.mcx_table_analyse.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), u32, C.POINTER(TableFacts)]
+        L.mcx_table_facts_of.argtypes = [vp, C.POINTER(TableFacts)]
+        if int(L.mcx_abi_version()) != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} has ABI version {L.mcx_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
         _lib = L
         return _lib
 
@@ -263,7 +280,7 @@ def make_desc(kind: int, k: int, dist_type: int, weight: bool = False, p_table: 
               cell_addr16: bool = False) -> ModuleDesc:
     if not block and os.environ.get("MCX_BLOCK"):        # tuning knob
         block = int(os.environ["MCX_BLOCK"])
-    return ModuleDesc(kind, k, dist_type, int(weight), int(p_table), int(q_table), int(guard_endpoints),
+    return ModuleDesc(C.sizeof(ModuleDesc), kind, k, dist_type, int(weight), int(p_table), int(q_table), int(guard_endpoints),
                       int(precise_sampler), int(block), int(tables_lds), int(rng), int(unit_params), int(second_moments),
                       int(walk), int(cell_tables), int(q_sampler), int(moment_family), int(user_tables), int(logpdf_analytic),
                       int(cdf_direct), int(cell_noclamp), int(cell_addr16))
@@ -292,6 +309,28 @@ def cell_pads_host(keys, dist_type: int, p1: float, p2: float, x_range=None, gua
     ok = load().mcx_cell_pads_host(keys.ctypes.data_as(C.POINTER(C.c_float)), len(keys), int(dist_type), float(p1), float(p2),
                                    int(x_range is not None), float(lo), float(hi), int(guard), C.byref(pl), C.byref(pr))
     return (pl.value, pr.value) if ok == 1 else None
+
+
+def table_facts(kind: int, keys, values) -> TableFacts:
+    """Everything mcx_table_create derives from a table before uploading it, without a device (include/mcx.h:
+    mcx_table_analyse): has_cells, direct_bits, guide_bits, lds_bytes, inv_dk, value range, reach_known."""
+    k = np.ascontiguousarray(keys, dtype=np.float32)
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    f = TableFacts(C.sizeof(TableFacts))
+    fp = C.POINTER(C.c_float)
+    check(load().mcx_table_analyse(int(kind), k.ctypes.data_as(fp), v.ctypes.data_as(fp), len(k), C.byref(f)))
+    return f
+
+
+def module_key(user_src: str, desc: ModuleDesc) -> str:
+    """Cache key of the code object (user_src, desc) compiles to: <cache dir>/<key>.hsaco (include/mcx.h: mcx_module_key)."""
+    buf = C.create_string_buffer(33)
+    check(load().mcx_module_key(user_src.encode(), C.byref(desc), buf))
+    return buf.value.decode()
+
+
+def cache_dir() -> str:
+    return (load().mcx_cache_dir() or b"").decode()
 
 
 def table_cells(keys, values):
@@ -544,7 +583,7 @@ class Engine:
                   target_pdf: Optional[Table] = None, proposal_pdf: Optional[Table] = None,
                   rank: int = 0, world: int = 1, d_sums: Optional[int] = None, stream: Optional[int] = None):
         """Returns (sums float64[K] or None when d_sums is given, n_eff)."""
-        p = IntegrateParams(int(n_samples), int(target_threads or 0), int(seed) & 0xFFFFFFFF, float(param1),
+        p = IntegrateParams(_SZ_INTEGRATE, 0, int(n_samples), int(target_threads or 0), int(seed) & 0xFFFFFFFF, float(param1),
                             float(param2), int(rank), int(world), self._ptr(cdf), self._ptr(target_pdf),
                             self._ptr(proposal_pdf))
         n_eff = C.c_uint64(0)
@@ -563,7 +602,7 @@ class Engine:
              stream: Optional[int] = None, x0: float = 0.0, target_accept: float = 0.44):
         """Returns (sums float64[result_rows(desc)] (row k, or 2k with second moments = accepted steps) or None,
         n_eff)."""
-        p = McmcParams(int(n_steps), int(n_chains), int(n_burnin), int(target_threads or 0),
+        p = McmcParams(_SZ_MCMC, int(n_steps), int(n_chains), int(n_burnin), int(target_threads or 0),
                        int(seed) & 0xFFFFFFFF, float(param1), float(param2), int(rank), int(world),
                        self._ptr(cdf), self._ptr(target_logpdf), self._ptr(proposal_logpdf), float(x0), float(target_accept))
         n_eff = C.c_uint64(0)
@@ -614,7 +653,7 @@ def _multi(fn_name: str, shards, make_params, ptype):
 def integrate_multi(shards, n_samples: int, seed: int, param1: float, param2: float, target_threads: Optional[int] = None):
     """Whole-grid sums from len(shards) engines driven by this thread. tables-dict keys: cdf, target_pdf, proposal_pdf."""
     def make(r, n, eng, tb):
-        return IntegrateParams(int(n_samples), int(target_threads or 0), int(seed) & 0xFFFFFFFF, float(param1), float(param2),
+        return IntegrateParams(_SZ_INTEGRATE, 0, int(n_samples), int(target_threads or 0), int(seed) & 0xFFFFFFFF, float(param1), float(param2),
                                r, n, Engine._ptr(tb.get("cdf")), Engine._ptr(tb.get("target_pdf")), Engine._ptr(tb.get("proposal_pdf")))
     return _multi("mcx_integrate_multi", shards, make, IntegrateParams)
 
@@ -623,7 +662,7 @@ def mcmc_multi(shards, n_steps: int, n_chains: int, n_burnin: int, seed: int, pa
                target_threads: Optional[int] = None, x0: float = 0.0, target_accept: float = 0.44):
     """Chain-sharded MH over len(shards) engines. tables-dict keys: cdf, target_logpdf, proposal_logpdf."""
     def make(r, n, eng, tb):
-        return McmcParams(int(n_steps), int(n_chains), int(n_burnin), int(target_threads or 0), int(seed) & 0xFFFFFFFF,
+        return McmcParams(_SZ_MCMC, int(n_steps), int(n_chains), int(n_burnin), int(target_threads or 0), int(seed) & 0xFFFFFFFF,
                           float(param1), float(param2), r, n, Engine._ptr(tb.get("cdf")), Engine._ptr(tb.get("target_logpdf")),
                           Engine._ptr(tb.get("proposal_logpdf")), float(x0), float(target_accept))
     return _multi("mcx_mcmc_multi", shards, make, McmcParams)
@@ -670,7 +709,7 @@ class Comm:
 
     def integrate(self, shards, n_samples: int, seed: int, param1: float, param2: float, target_threads: Optional[int] = None):
         n = len(shards)
-        params = [IntegrateParams(int(n_samples), int(target_threads or 0), int(seed) & 0xFFFFFFFF, float(param1), float(param2),
+        params = [IntegrateParams(_SZ_INTEGRATE, 0, int(n_samples), int(target_threads or 0), int(seed) & 0xFFFFFFFF, float(param1), float(param2),
                                   r, n, Engine._ptr(tb.get("cdf")), Engine._ptr(tb.get("target_pdf")),
                                   Engine._ptr(tb.get("proposal_pdf"))) for r, (_, _, tb) in enumerate(shards)]
         return self._call("mcx_integrate_comm", shards, params, IntegrateParams)
@@ -678,7 +717,7 @@ class Comm:
     def mcmc(self, shards, n_steps: int, n_chains: int, n_burnin: int, seed: int, param1: float, param2: float,
              target_threads: Optional[int] = None, x0: float = 0.0, target_accept: float = 0.44):
         n = len(shards)
-        params = [McmcParams(int(n_steps), int(n_chains), int(n_burnin), int(target_threads or 0), int(seed) & 0xFFFFFFFF,
+        params = [McmcParams(_SZ_MCMC, int(n_steps), int(n_chains), int(n_burnin), int(target_threads or 0), int(seed) & 0xFFFFFFFF,
                              float(param1), float(param2), r, n, Engine._ptr(tb.get("cdf")), Engine._ptr(tb.get("target_logpdf")),
                              Engine._ptr(tb.get("proposal_logpdf")), float(x0), float(target_accept))
                   for r, (_, _, tb) in enumerate(shards)]
