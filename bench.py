@@ -17,7 +17,11 @@ ever exec'ed from a process that has touched the GPU.
 
 Other configs (BASELINE.json configs[2..4]): c3 importance sampling with a 512-point target table, c4
 chain-sharded Metropolis-Hastings (1 048 576 chains x 11 000 steps), c5 K = 32 moments of Beta(2,5) at 1e10
-samples. Default scaling: c2 / c3 weak (nominal size per GPU), c4 / c5 strong (BASELINE fixes the total).
+samples. Default scaling: c2 / c3 weak (nominal size per GPU), c4 / c5 strong (BASELINE fixes the total). The default
+command times ALL of them: c2 is the headline (`value`), c3 / c4 / c5 run through the same timed loop right after it
+and are reported under `configs` in the same JSON line (--legs), each with its own kernel time, roofline, accuracy on
+both streams and a short CPU-baseline slice. At N > 1 the line also carries `self_check`: an RCCL all-reduce of ones
+(= N) and, per config, the all-reduced shard sums against the whole grid run on rank 0 (`sharded_equals_single`).
 """
 import argparse
 import json
@@ -63,10 +67,15 @@ def parse_args(argv=None):
                          "the CUs the previous step's tail leaves idle (measured 0.420 -> 0.397 ms per step); the default "
                          "stays 1 so that a launch's duration in the rocprofv3 trace is the kernel alone, not two "
                          "launches sharing the chip")
-    ap.add_argument("--mcmc-segments", type=int, default=0,
-                    help="c4 only, opt-in: run each MCMC call as two chain halves on two streams x this many step segments "
-                         "(mcx_engine_set_mcmc_segments; measured 8.5 -> 8.0 ms at 8). Default 0: one launch per call, so "
-                         "that a traced launch is the whole call")
+    ap.add_argument("--mcmc-segments", type=int, default=None,
+                    help="c4: run each MCMC call as two chain halves on two streams x this many step segments "
+                         "(mcx_engine_set_mcmc_segments; measured 8.5 -> 8.0 ms at 8). Default: libmcx's own rule (8 segments for "
+                         "launches of >= 1 048 576 chains); 0 = one launch per call")
+    ap.add_argument("--legs", default="auto",
+                    help="other BASELINE configs timed in the same run and reported under `configs` in the one JSON line: "
+                         "auto (c3,c4,c5 when --config c2 at full scale and not under rocprofv3), none, or a comma list")
+    ap.add_argument("--leg-steps", type=int, default=20, help="timed steps per leg (capped by --steps)")
+    ap.add_argument("--leg-cpu-seconds", type=float, default=2.5, help="wall-clock budget of each leg's CPU baseline slice")
     ap.add_argument("--rng", default="pcg_ref", help="stream of the headline loop: pcg_ref (the reference's) or philox")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the measured configuration) or gloo (rehearsal)")
     ap.add_argument("--single-device", action="store_true",
@@ -316,55 +325,79 @@ def accuracy(np, wl, out_rows, n_eff):
     return d
 
 
-def run_rank(args):
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+class Ctx:
+    """What every config leg of one rank shares: the process group, the device, the product's classes."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    if args.rehearse_cpu:
-        return run_rehearsal(args, rank, world)
-    # cold-start probe: a child of rank 0, started before this process touches the GPU (a parent launcher has already
-    # run it and handed the result down)
-    cold = json.loads(os.environ["MCX_BENCH_COLD"]) if "MCX_BENCH_COLD" in os.environ else (cold_probe(args) if rank == 0 else None)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
-    if args.single_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(args.backend)
+    def __init__(self, args, torch, dist, np, world, rank, local_rank, device):
+        import baseline_configs as bc
+        from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+        from wgpu_montecarlo import runtime as rt
 
-    import baseline_configs as bc
-    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
-    from wgpu_montecarlo import runtime as _rt
+        self.args, self.torch, self.dist, self.np = args, torch, dist, np
+        self.world, self.rank, self.local_rank, self.device = world, rank, local_rank, device
+        self.bc, self.Distribution, self.MonteCarloIntegrator, self.rt = bc, Distribution, MonteCarloIntegrator, rt
+        self.group = "world" if world > 1 else None
 
-    wl = bc.get(args.config, Distribution)
-    scaling = args.scaling or DEFAULT_SCALING[args.config]
+
+def uniform_draws_per_step(name, wl, units_per_step):
+    """Uniforms one step draws from the counter stream: the reference's hash takes a 32-bit counter,
+    so beyond 2^32 draws per call its estimates stop converging and only the Philox stream keeps the 3-sigma claim."""
+    return 2 * units_per_step if name == "c4" else units_per_step      # MH step: one proposal + one accept uniform
+
+
+def sharded_equals_single(ctx, wl, prepared, n_step, n_eff):
+    """N > 1 self-check of the sharding itself: the all-reduced sums of the rank shards against the SAME logical grid run
+    whole on rank 0 (shard = (0, 1)). The samples are identical by construction (global (seed, idx, iter) counters);
+    only the summation order differs, so the means agree to ~1e-9 -- a dropped or double-counted shard boundary
+    (one unit of every logical thread) would move E[x^2] by >= 1e-4 relative. MCMC: the accepted-step counts, integers,
+    must agree exactly."""
+    torch, dist, np = ctx.torch, ctx.dist, ctx.np
+    seed = 4242
+    sharded = torch.zeros(wl.rows, dtype=torch.float64, device=ctx.device)
+    wl.launch(prepared, n_step, seed, sharded)                       # shards + blocking all-reduce
+    single = torch.zeros(wl.rows, dtype=torch.float64, device=ctx.device)
+    if ctx.rank == 0:
+        wl.launch(prepared, n_step, seed, single, shard=(0, 1))      # the whole grid on this GPU, no collective
+    torch.cuda.synchronize()
+    dist.barrier()
+    if ctx.rank != 0:
+        return None
+    a, b = sharded.cpu().numpy() / float(n_eff), single.cpu().numpy() / float(n_eff)
+    truth, band = wl.band(n_eff, 0.66) if wl.n_steps else wl.band(n_eff)
+    scale = np.abs(truth) + band * np.sqrt(float(n_eff)) / 3.0      # |mean| + one standard deviation of the integrand
+    rel = np.abs(a[:wl.k] - b[:wl.k]) / scale
+    ok = bool(np.all(rel <= 1e-7))
+    d = dict(ok=ok, max_mean_diff_over_scale=float(rel.max()), tolerance=1e-7, seed=seed,
+             what="all-reduced shard sums vs the whole grid on rank 0 (shard=(0,1)), same seed")
+    if wl.n_steps:
+        d["accepted_steps_equal"] = bool(sharded[wl.k].item() == single[wl.k].item())
+        d["ok"] = ok and d["accepted_steps_equal"]
+    return d
+
+
+def measure_config(ctx, name, steps, warmup, primary, cpu_seconds):
+    """One BASELINE config through the same timed loop: reference stream, Philox stream, the dominant kernel's time and
+    roofline, the blocking API call, the N > 1 self-check, the CPU baseline. Returns the leg's dict (rank 0) or None."""
+    args, torch, dist, np, world, rank = ctx.args, ctx.torch, ctx.dist, ctx.np, ctx.world, ctx.rank
+    bc, device = ctx.bc, ctx.device
+    wl = bc.get(name, ctx.Distribution)
+    scaling = (args.scaling if primary else None) or DEFAULT_SCALING[name]
     nominal = wl.nominal
-    if args.samples_per_gpu is not None and args.config == "c2":
+    if primary and args.samples_per_gpu is not None and name == "c2":
         nominal = int(args.samples_per_gpu)
     n_step = int(nominal * args.scale) * (world if scaling == "weak" else 1)        # size of one step, whole job
-    group = "world" if world > 1 else None
+    n_streams = args.streams if primary else 1
 
     def make(rng):
-        mc = MonteCarloIntegrator(device=local_rank, rng=rng, process_group=group)
-        if args.target_phys:
+        mc = ctx.MonteCarloIntegrator(device=ctx.local_rank, rng=rng, process_group=ctx.group)
+        if primary and args.target_phys:
             mc._engine.set_target_threads(args.target_phys)
-        if args.mcmc_segments:
+        if args.mcmc_segments is not None:
             mc._engine.set_mcmc_segments(args.mcmc_segments)
         return mc, wl.prepare(mc)
 
     integ, prepared = make(args.rng)
-    out = torch.zeros(args.warmup + args.steps + 1, wl.rows, dtype=torch.float64, device=device)
+    out = torch.zeros(warmup + steps + 1, wl.rows, dtype=torch.float64, device=device)
 
     def prewarm(prep):
         """Device warm-up, untimed and outside the W + K steps: after process start-up the GPU sits in its idle clock
@@ -382,8 +415,8 @@ def run_rank(args):
         return launched
 
     prewarm_steps = prewarm(prepared)
-    elapsed, n_eff = timed_loop(torch, dist, world, wl, prepared, n_step, out, args.warmup, args.steps, args.streams, device)
-    acc = accuracy(np, wl, out[args.warmup:args.warmup + args.steps].cpu().numpy(), n_eff)
+    elapsed, n_eff = timed_loop(torch, dist, world, wl, prepared, n_step, out, warmup, steps, n_streams, device)
+    acc = accuracy(np, wl, out[warmup:warmup + steps].cpu().numpy(), n_eff)
 
     # the same loop on the Philox stream: beyond 2^32 uniforms per step (8 ranks x 1e9 samples; C4; C5) the reference's
     # 32-bit counter hash is oversubscribed and its estimates stop converging -- report both
@@ -392,14 +425,16 @@ def run_rank(args):
         _, prepared_px = make("philox")
         prewarm(prepared_px)
         out_px = torch.zeros_like(out)
-        el_px, n_eff_px = timed_loop(torch, dist, world, wl, prepared_px, n_step, out_px, min(args.warmup, 3),
-                                     args.steps, args.streams, device)
-        philox = dict(value=wl.units(n_eff_px) * args.steps / el_px, ms_per_step=el_px / args.steps * 1e3,
-                      **accuracy(np, wl, out_px[min(args.warmup, 3):min(args.warmup, 3) + args.steps].cpu().numpy(), n_eff_px))
+        w_px = min(warmup, 3)
+        el_px, n_eff_px = timed_loop(torch, dist, world, wl, prepared_px, n_step, out_px, w_px, steps, n_streams, device)
+        philox = dict(value=wl.units(n_eff_px) * steps / el_px, ms_per_step=el_px / steps * 1e3,
+                      **accuracy(np, wl, out_px[w_px:w_px + steps].cpu().numpy(), n_eff_px))
 
-    # dominant kernel: R launches of this rank's shard back to back on the stream they run on, NO collective, one
-    # HIP-event pair around all of them -> per-launch time of main + fold kernel including launch gaps
-    reps = max(10, min(args.steps, 40))
+    # dominant kernel: R calls of this rank's shard back to back on the stream they run on, NO collective, one
+    # HIP-event pair around all of them -> per-call time of main (+ side-stream segments) + fold kernel including
+    # launch gaps. A time-segmented MCMC call is S x 2 launches on two streams joined before the fold: the event pair
+    # on the calling stream brackets all of them.
+    reps = max(10, min(steps, 40))
     scratch = torch.zeros(wl.rows, dtype=torch.float64, device=device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     wl.launch(prepared, n_step, 7, scratch, reduce=False)
@@ -421,129 +456,298 @@ def run_rank(args):
 
     units_per_step = wl.units(n_eff)
     units_per_launch = units_per_step / world                   # this rank's shard
-    ops = bc.OPS_PER_UNIT[args.config]
+    try:
+        module_key = ctx.rt.module_key(prepared._plan.module.user_src, prepared._plan.desc)
+    except Exception:                                # noqa: BLE001 -- the key only selects which profile entry is quoted
+        module_key = None
+    ops, ops_source = bc.ops_per_unit(name, module_key)
     valu_achieved = units_per_launch * ops / (kernel_ms * 1e-3)
-    hbm_bytes = launch["n_blocks"] * launch["launches"] * wl.rows * 8.0       # one rows*8-byte record per workgroup
+    # algorithmic HBM bytes of one call: one rows*8-byte record per workgroup per launch; a time-segmented MCMC call (S x 2
+    # launches; last_launch reports the workgroups of one segment, both halves) also carries {x, w} = 8 bytes per chain
+    # through HBM between segments: S writes + (S - 1) reads
+    segments = launch.get("segments", 0)
+    records = launch["n_blocks"] * (segments if segments else max(launch["launches"], 1))
+    hbm_bytes = records * wl.rows * 8.0
+    if segments:
+        hbm_bytes += (n_eff // wl.n_steps) / world * 8.0 * (2 * segments - 1)
     hbm_gbps = hbm_bytes / (kernel_ms * 1e-3) / 1e9
 
-    # blocking Python-API latency for the same call (emission + launch + D2H of the K doubles), rank-local
+    check = sharded_equals_single(ctx, wl, prepared, n_step, n_eff) if world > 1 else None
+
+    # blocking Python-API latency for the same call (plan-cache lookup + launch + the K doubles back), rank-local
     api = None
     if world == 1:
         api_times = []
-        for _ in range(6):
+        for _ in range(8):
             t1 = time.perf_counter()
             res = wl.blocking(integ, n_step, 42)
             api_times.append((time.perf_counter() - t1) * 1e3)
-        api = dict(api_first_call_ms=api_times[0], api_call_ms=float(np.median(api_times[1:])), api_values=res.values[:4].tolist())
+        api = dict(api_first_call_ms=api_times[0], api_call_ms=float(np.median(api_times[2:])), api_values=res.values[:4].tolist())
 
-    line = None
-    if rank == 0:
-        value = units_per_step * args.steps / elapsed
-        backend = "RCCL" if args.backend == "nccl" else args.backend
-        # HBM traffic and executed instruction counts of this kernel come from separate rocprofv3 --pmc passes of this
-        # same command (tools/profile_all.sh -> profiles/r02_pmc_summary.txt); quoted only when that profile was taken
-        # with the launch geometry of this run, else null
-        traffic, pmc = None, pmc_summary(args.config, launch, world)
-        if pmc:
-            traffic = pmc.get("hbm_bytes_per_launch_corrected")
-        line = {
-            "metric": "samples/sec (whole node), K=4 fused functions on N(0,1)" if args.config == "c2" else
-                      f"{wl.unit} (whole node), BASELINE config {args.config}",
-            "value": value,
-            "unit": wl.unit,
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "device_prewarm": {"ms": args.prewarm_ms, "steps": prewarm_steps,
-                               "note": "untimed launches of the same step before the W warm-up steps, so that the W + K steps "
-                                       "do not run on the idle clock state the GPU is in after process start-up"},
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": scaling,
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": wl.title + f"; logical grid T={'1048576 chains' if args.config == 'c4' else 65536}; "
-                            f"{scaling} scaling: {n_step:.4g} {'chains' if args.config == 'c4' else 'samples'} per step over {world} GPU(s)",
-                "name": args.config,
-                "size_per_step": n_step,
-                "n_eff_per_step": int(n_eff),
-                "units_per_step": int(units_per_step),
-                "parallelism": (f"{'chain' if args.config == 'c4' else 'sample-grid'} shards x{world}, one {backend} "
-                                f"sum all-reduce of {wl.rows} f64 per step") if world > 1 else "single GPU",
-                "accumulate": "f32 registers per <= 128 units -> f64",
-                "rng": args.rng, "streams": args.streams, "mcmc_segments": args.mcmc_segments,
-                "hip_runtime": _rt.hip_runtime(),
-            },
-            "rccl_ranks": dist.get_world_size() if (world > 1 and args.backend == "nccl") else None,
-            "collective_backend": args.backend if world > 1 else None,
-            **acc,
-            "per_gpu_units_per_s": value / world,
-            "philox": philox,
-            "cold": cold,
-            "roofline": {
-                "bound": "valu",
-                "achieved": valu_achieved / 1e12,
-                "peak": bc.VALU_PEAK_LANEOPS / 1e12,
-                "unit": "Tlane-op/s",
-                "frac": valu_achieved / bc.VALU_PEAK_LANEOPS,
-                "traffic": traffic,
-                "kernel": "mcx_mcmc_kernel" if args.config == "c4" else "mcx_integrate_kernel",
-                "kernel_ms": kernel_ms,
-                "kernel_ms_method": f"{reps} launches of this rank's shard (main + fold kernel, no collective) back to back "
-                                    f"on one stream, one HIP-event pair around all of them",
-                "per_rank_kernel_ms": per_rank_kernel_ms,
-                "ops_per_unit": ops,
-                "executed_valu_per_unit": pmc.get("valu_inst_per_unit") if pmc else None,
-                "valu_issue_frac_of_peak": pmc.get("valu_issue_frac_of_peak") if pmc else None,
-                "pmc_source": "profiles/r02_pmc_summary.txt (FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes; SQ_INSTS_VALU)" if pmc else None,
-                "units_per_launch": units_per_launch,
-                "launch": launch,
-                "note": "the binding resource of these fused kernels is vector-ALU issue (SURVEY.md 8d): ops_per_unit is "
-                        "the ALGORITHMIC lane-op count of the config (DESIGN.md 4, tools/baseline_configs.py), peak = "
-                        "256 CU x 4 SIMD x 32 lanes x 2.4 GHz; executed-instruction counts are in profiles/r02_*_pmc_*; "
-                        "the HBM view of the same launch is in roofline_hbm",
-            },
-            # the same kernel against the HBM roofline, in the generic schema: algorithmic bytes = rows * 8 B per workgroup
-            "roofline_hbm": {"bound": "hbm", "achieved": hbm_gbps, "peak": bc.HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": hbm_gbps / bc.HBM_PEAK_GBPS, "traffic": traffic,
-                             "algorithmic_bytes_per_launch": hbm_bytes,
-                             "note": "the kernel writes one rows*8-byte record per workgroup and reads only code, arguments "
-                                     "and <= 56 KiB of tables (staged into LDS once per workgroup, L2-resident): HBM is "
-                                     "~1e-5 of peak by design, not the bound"},
-        }
-        if api:
-            line.update(api)
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
+    if rank != 0:
+        return None
+    value = units_per_step * steps / elapsed
+    backend = "RCCL" if args.backend == "nccl" else args.backend
+    draws = uniform_draws_per_step(name, wl, units_per_step)
+    # HBM traffic and executed instruction counts of this kernel come from separate rocprofv3 --pmc passes of this same
+    # command (tools/profile_all.sh -> profiles/rNN_pmc_summary.txt); quoted only when that profile was taken with the
+    # launch geometry of this run, else null
+    traffic, pmc = None, pmc_summary(name, launch, world)
+    if pmc:
+        traffic = pmc.get("hbm_bytes_per_launch_corrected")
+    leg = {
+        "metric": "samples/sec (whole node), K=4 fused functions on N(0,1)" if name == "c2" else
+                  f"{wl.unit} (whole node), BASELINE config {name}",
+        "value": value,
+        "unit": wl.unit,
+        "steps": steps,
+        "warmup": warmup,
+        "device_prewarm": {"ms": args.prewarm_ms, "steps": prewarm_steps,
+                           "note": "untimed launches of the same step before the W warm-up steps, so that the W + K steps "
+                                   "do not run on the idle clock state the GPU is in after process start-up"},
+        "ms_per_step": elapsed / steps * 1e3,
+        "scaling": scaling,
+        "config": {
+            "workload": wl.title + f"; logical grid T={'1048576 chains' if name == 'c4' else 65536}; "
+                        f"{scaling} scaling: {n_step:.4g} {'chains' if name == 'c4' else 'samples'} per step over {world} GPU(s)",
+            "name": name,
+            "size_per_step": n_step,
+            "n_eff_per_step": int(n_eff),
+            "units_per_step": int(units_per_step),
+            "parallelism": (f"{'chain' if name == 'c4' else 'sample-grid'} shards x{world}, one {backend} "
+                            f"sum all-reduce of {wl.rows} f64 per step") if world > 1 else "single GPU",
+            "accumulate": "f32 registers per <= 128 units -> f64",
+            "rng": args.rng, "streams": n_streams,
+            "mcmc_segments": "auto" if args.mcmc_segments is None else args.mcmc_segments,
+            "hip_runtime": ctx.rt.hip_runtime(),
+        },
+        **acc,
+        "uniform_draws_per_step": int(draws),
+        # which stream the 3-sigma claim holds for at this size, by construction (not by this run's luck): the reference's
+        # counter hash has 2^32 distinct inputs, Philox 2^128
+        "stream_valid": {"pcg_ref": bool(draws <= 2**32), "philox": True},
+        "per_gpu_units_per_s": value / world,
+        "philox": philox,
+        "roofline": {
+            "bound": "valu",
+            "achieved": valu_achieved / 1e12,
+            "peak": bc.VALU_PEAK_LANEOPS / 1e12,
+            "unit": "Tlane-op/s",
+            "frac": valu_achieved / bc.VALU_PEAK_LANEOPS,
+            "traffic": traffic,
+            "kernel": "mcx_mcmc_kernel" if name == "c4" else "mcx_integrate_kernel",
+            "kernel_ms": kernel_ms,
+            "kernel_ms_method": f"{reps} calls of this rank's shard (main + fold kernel, no collective) back to back "
+                                f"on one stream, one HIP-event pair around all of them",
+            "per_rank_kernel_ms": per_rank_kernel_ms,
+            "ops_per_unit": ops,
+            "ops_per_unit_source": ops_source,
+            "executed_valu_per_unit": pmc.get("valu_inst_per_unit") if pmc else None,
+            "valu_issue_frac_of_peak": pmc.get("valu_issue_frac_of_peak") if pmc else None,
+            "pmc_source": f"profiles/{pmc['_file']} (FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes; SQ_INSTS_VALU)" if pmc else None,
+            "issue_model": issue_model(ctx, module_key, kernel_ms, units_per_launch, pmc),
+            "units_per_launch": units_per_launch,
+            "launch": launch,
+            "note": "the binding resource of these fused kernels is vector-ALU issue (SURVEY.md 8d): ops_per_unit = the hot "
+                    "loop of the code object that ran, in lane-op equivalents with the survey's weights (plain op 1, integer "
+                    "multiply 4, transcendental 2; tools/issue_model.py), peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; "
+                    "issue_model prices the same instructions with the measured per-class issue costs; the HBM view of the "
+                    "same launch is in roofline_hbm",
+        },
+        # the same kernel against the HBM roofline, in the generic schema: algorithmic bytes = rows * 8 B per workgroup
+        "roofline_hbm": {"bound": "hbm", "achieved": hbm_gbps, "peak": bc.HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": hbm_gbps / bc.HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": hbm_bytes,
+                         "note": "the kernel writes one rows*8-byte record per workgroup and reads only code, arguments "
+                                 "and <= 72 KiB of tables (staged into LDS once per workgroup, L2-resident): HBM is "
+                                 "~1e-5 of peak by design, not the bound"},
+    }
+    if check is not None:
+        leg["sharded_equals_single"] = check
+    if api:
+        leg.update(api)
+    if not args.no_cpu_baseline and world == 1:
+        leg["cpu_baseline"] = cpu_baseline(name, cpu_seconds)
+        if name == "c2":
+            leg["cpu_baseline_numpy"] = cpu_baseline_numpy(min(cpu_seconds, 4.0))
+    return leg
+
+
+def issue_model(ctx, key, kernel_ms, units_per_launch, pmc):
+    """SIMD-cycles per wave-unit, measured against modelled. measured = kernel time x clock x 1024 SIMDs / wave-units;
+    modelled = sum over instruction classes of (count in the hot loop of THIS module's code object) x (issue cost of the
+    class, profiles/r02_valu_issue_microbench.txt). The class counts are read from profiles/rNN_issue_model.json, which
+    tools/issue_model.py writes from the disassembly of the cached code object and which names that object by its cache
+    key: a module whose key is not in the file (kernel changed since) reports modelled = null rather than a stale figure."""
+    path = latest_profile("issue_model.json")
+    clock = (pmc or {}).get("effective_clock_ghz") or ctx.bc.NOMINAL_CLOCK_GHZ
+    wave_units = units_per_launch / 64.0
+    measured = kernel_ms * 1e-3 * clock * 1e9 * 1024.0 / wave_units
+    out = dict(cycles_per_unit_measured=measured, clock_ghz=clock,
+               clock_source="GRBM_GUI_ACTIVE of the committed PMC pass" if (pmc or {}).get("effective_clock_ghz") else "nominal",
+               module_key=key, cycles_per_unit_modelled=None, source=None)
+    if path is None or key is None:
+        return out
+    try:
+        table = json.loads(path.read_text())
+    except ValueError:
+        return out
+    entry = table.get("modules", {}).get(key)
+    if entry:
+        out.update(cycles_per_unit_modelled=entry["cycles_per_unit_modelled"], classes_per_unit=entry["classes_per_unit"],
+                   class_costs=table.get("class_costs"), source=f"profiles/{path.name}")
+    return out
+
+
+def latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that has one."""
+    hits = sorted((ROOT / "profiles").glob(f"r[0-9][0-9]_{suffix}"))
+    return hits[-1] if hits else None
+
+
+def cpu_baseline_numpy(target_seconds):
+    """The 'benchmark.py-style' figure of SURVEY.md 8(d)(ii): the reference's own CPU comparison is a numpy / Python loop
+    on ONE core (examples/benchmark.py:43-68). Here: oracle/numpy_port.py, a vectorised numpy restatement of the C2
+    kernel on the reference's counter stream, single-threaded."""
+    import numpy as np
+
+    from oracle import numpy_port as npp
+
+    t0 = time.perf_counter()
+    npp.normal_moments(4, 2_000_000, seed=1)
+    rate = 2_000_000 / (time.perf_counter() - t0)
+    n = int(min(max(rate * target_seconds, 2_000_000), 2e9))
+    t0 = time.perf_counter()
+    sums, n_eff = npp.normal_moments(4, n, seed=42)
+    dt = time.perf_counter() - t0
+    return dict(value=n_eff / dt, unit="samples/s", cores=1, kind="port",
+                sample=f"K=4 moments on N(0,1): n_samples={n:.3g} of the c2 workload, oracle/numpy_port.py (vectorised numpy "
+                       f"restatement of the reference kernel, f32 terms, same counter stream), one core, {dt:.1f} s wall",
+                mean_error_vs_truth=[float(v) for v in (sums / n_eff - np.array([0.0, 1.0, 0.0, 3.0]))])
+
+
+def leg_names(args):
+    """BASELINE configs timed next to the headline in the same line (the driver only ever runs the default command)."""
+    if args.legs == "none":
+        return []
+    if args.legs != "auto":
+        return [c for c in args.legs.replace(" ", "").split(",") if c and c != args.config]
+    if args.config != "c2" or under_profiler() or args.scale != 1.0:
+        return []
+    return ["c3", "c4", "c5"]
+
+
+def run_rank(args):
+    import datetime
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if args.rehearse_cpu:
+        return run_rehearsal(args, rank, world)
+    # cold-start probe: a child of rank 0, started before this process touches the GPU (a parent launcher has already
+    # run it and handed the result down)
+    cold = json.loads(os.environ["MCX_BENCH_COLD"]) if "MCX_BENCH_COLD" in os.environ else (cold_probe(args) if rank == 0 else None)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    if args.single_device:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        # a desynchronised rank must end the job, not hang it: collectives give up after 5 minutes
+        timeout = datetime.timedelta(seconds=300)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device, timeout=timeout)
+        else:
+            dist.init_process_group(args.backend, timeout=timeout)
+
+    ctx = Ctx(args, torch, dist, np, world, rank, local_rank, device)
+    t_start = time.perf_counter()
+
+    # N > 1: is the collective the RCCL one, and does it add up? An all-reduce of 1.0 over the group must give `world`.
+    rccl_sum_of_ones = None
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.float64, device=device)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rccl_sum_of_ones = float(ones.item())
+
+    line = measure_config(ctx, args.config, args.steps, args.warmup, True, args.cpu_seconds)
+    legs = {}
+    for name in leg_names(args):
+        # legs share the headline's process group: every rank runs the same deterministic code, so a failure (a module
+        # that does not compile, an invalid launch) is raised on all ranks at the same point and recorded, not fatal
+        try:
+            legs[name] = measure_config(ctx, name, min(args.steps, args.leg_steps), min(args.warmup, 3), False, args.leg_cpu_seconds)
+        except Exception as exc:                     # noqa: BLE001 -- the headline must survive a broken leg
+            legs[name] = {"error": f"{type(exc).__name__}: {exc}"[:600]}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        backend = "RCCL" if args.backend == "nccl" else args.backend
+        line.update({
+            "n_gpus": world,
+            "higher_is_better": True,
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "rccl_ranks": world if (world > 1 and args.backend == "nccl") else None,
+            "collective_backend": args.backend if world > 1 else None,
+            "cold": cold,
+            "configs": legs,
+            "self_check": None if world == 1 else {
+                "rccl_sum_of_ones": rccl_sum_of_ones,
+                "rccl_sum_of_ones_ok": rccl_sum_of_ones == float(world),
+                "collective": backend,
+                "sharded_equals_single": {n: (l or {}).get("sharded_equals_single") for n, l in [(args.config, line)] + list(legs.items())},
+            },
+            "bench_wall_s": time.perf_counter() - t_start,
+        })
+        # key order: the contract's keys first
+        head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config"]
+        ordered = {k: line[k] for k in head if k in line}
+        ordered.update({k: v for k, v in line.items() if k not in ordered})
         sys.stdout.flush()
-        print(json.dumps(line), flush=True)
+        print(json.dumps(ordered), flush=True)
 
 
 def pmc_summary(config, launch, world):
-    """The committed PMC digest of this config's kernel (profiles/r02_pmc_summary.txt), if its launch geometry matches."""
-    path = ROOT / "profiles" / "r02_pmc_summary.txt"
-    if world != 1 or not path.exists():
+    """The committed PMC digest of this config's kernel (profiles/rNN_pmc_summary.txt, latest round), if its launch
+    geometry matches this run: same workgroup size, same grid, same number of launches per call."""
+    path = latest_profile("pmc_summary.txt")
+    if world != 1 or path is None:
         return None
     for text in path.read_text().splitlines():
         try:
             d = json.loads(text)
         except ValueError:
             continue
-        if d.get("config") == config and str(d.get("workgroup")) == str(launch["block"]) and \
-                str(d.get("grid")) == str(launch["n_blocks"] * launch["block"]) and launch["launches"] == 1:
+        if d.get("config") != config or str(d.get("workgroup")) != str(launch["block"]):
+            continue
+        if int(d.get("launches_per_call", 1)) != max(launch["launches"], 1):
+            continue
+        grid = launch["n_blocks"] * launch["block"]
+        if str(d.get("grid")) == str(grid) or str(d.get("grid_per_segment")) == str(grid):
+            d["_file"] = path.name
             return d
     return None
 
 
 def prewarm_cache():
-    """hiprtc-compile the bench / smoke modules into the in-tree code-object cache (needs no GPU)."""
+    """hiprtc-compile the modules bench.py and smoke() launch into the in-tree code-object cache (needs no GPU): every
+    BASELINE config on both streams -- through the product's own planner (MonteCarloIntegrator.planner), so the descs
+    are the ones a GPU run builds --, the MCMC workgroup-size variants a chain-sharded run selects, and the K = 4 base
+    modules of each sampler."""
     import baseline_configs as bc
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
     from wgpu_montecarlo import runtime as rt
     from wgpu_montecarlo.api import functions_to_hip
 
@@ -551,8 +755,18 @@ def prewarm_cache():
     src = functions_to_hip(bc.moment_functions(4))
     for dist in (rt.DIST_UNIFORM, rt.DIST_NORMAL, rt.DIST_EXPONENTIAL, rt.DIST_CUSTOM):
         rt.precompile(src, rt.make_desc(rt.KIND_INTEGRATE, K, dist))
-    rt.precompile(src, rt.make_desc(rt.KIND_INTEGRATE, K, rt.DIST_NORMAL, unit_params=True))      # N(0,1): the headline
-    rt.precompile(src, rt.make_desc(rt.KIND_INTEGRATE, K, rt.DIST_NORMAL, unit_params=True, rng=rt.RNG_PHILOX))
+    built = {}
+    for rng in ("pcg_ref", "philox"):
+        mc = MonteCarloIntegrator.planner(rng=rng)
+        for name in ("c2", "c3", "c4", "c5"):
+            wl = bc.get(name, Distribution)
+            prepared = wl.prepare(mc)
+            built[(name, rng)] = prepared._plan.module.key
+            if name == "c4":
+                for parts in (2, 4, 8):             # a rank's share of 1 048 576 chains picks its workgroup size
+                    prepared._select(wl.nominal, shard=(0, parts))
+                    built[(name, rng, parts)] = prepared._plan.module.key
+    return built
 
 
 def main(argv=None):

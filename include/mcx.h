@@ -121,6 +121,16 @@ int  mcx_engine_device(const mcx_engine* e);
 float mcx_engine_last_kernel_ms(mcx_engine* e);
 /* Launch geometry of the last call: physical workgroups, threads per workgroup, dynamic LDS bytes. */
 int  mcx_engine_last_launch(mcx_engine* e, uint32_t* n_blocks, uint32_t* block, uint32_t* lds_bytes);
+/* Everything the three getters above and below report, in one call (what a binding reads after every blocking call). */
+typedef struct mcx_call_info {
+    uint32_t struct_size;      /* sizeof(mcx_call_info) in the caller's build */
+    uint32_t n_blocks, block, lds_bytes, launches;
+    float    kernel_ms;        /* < 0 if nothing was launched */
+    uint32_t segments;         /* MCMC: time segments the call ran as (launches = 2 x segments, n_blocks = the workgroups of
+                                * one segment, both halves), 0 for an unsegmented call */
+} mcx_call_info;
+/* with_timing = 0 leaves kernel_ms at -1 and does not wait; 1 waits for the call's timing event like mcx_engine_last_kernel_ms */
+int  mcx_engine_last_call(mcx_engine* e, mcx_call_info* out, int with_timing);
 /* Main-kernel launches the last call was split into (1 unless the call exceeded the per-launch work bound of
  * ~1e11 samples / chain-steps, MCX_MAX_LAUNCH_UNITS; the reference always issues one dispatch, src/engine.rs:468-525). */
 uint32_t mcx_engine_last_launch_count(const mcx_engine* e);
@@ -260,6 +270,8 @@ int  mcx_module_key(const char* user_src, const mcx_module_desc* desc, char* key
 int  mcx_module_source(const char* user_src, const mcx_module_desc* desc, char** out_text);
 void mcx_free(void* p);
 void mcx_module_release(mcx_module* m);
+/* Threads per workgroup the module was compiled for (desc.block, or the default libmcx chose for block = 0). */
+uint32_t mcx_module_block(const mcx_module* m);
 /* Static LDS bytes of the module's main kernel (its cross-wave reduction scratch), read from the code object. */
 uint32_t mcx_module_static_lds(const mcx_module* m);
 /* LDS bytes a module built from `desc` leaves for staged tables: 160 KiB per CU minus (an upper bound of) the static

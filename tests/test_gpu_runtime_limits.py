@@ -228,7 +228,7 @@ def test_launch_geometry_follows_the_work_per_workgroup(integrator):
 
 @pytest.mark.parametrize("segments", [2, 5, 8])
 def test_mcmc_time_segments_run_the_same_chains(integrator, segments):
-    """Opt-in mcx_engine_set_mcmc_segments: two halves of the chains on two streams, each cut into step segments that
+    """mcx_engine_set_mcmc_segments with an explicit count: two halves of the chains on two streams, each cut into step segments that
     resume every chain from its saved {x, w}. The draws are functions of (seed, chain, step), so the chains are the SAME
     chains: accepted-step count identical, sums equal up to the regrouping of the f32 accumulation blocks -- for odd and
     even burn-in lengths, step counts that leave a single trailing step, chain counts that do not halve into whole
@@ -260,7 +260,7 @@ def test_mcmc_time_segments_run_the_same_chains(integrator, segments):
                                           proposal_kind="random_walk")
         assert eng.last_launch()["launches"] == 1 and np.all(np.isfinite(other.values))
     finally:
-        eng.set_mcmc_segments(0)
+        eng.set_mcmc_segments(rt.SEGMENTS_AUTO)
     assert launches == 2 * min(segments, (37 + 100) // 4) or launches == 2 * segments
     for a, b, (s, c, bn) in zip(plain, cut, cases):
         assert a.meta["n_eff"] == b.meta["n_eff"]
@@ -270,3 +270,69 @@ def test_mcmc_time_segments_run_the_same_chains(integrator, segments):
     assert np.allclose(out.cpu().numpy()[:2] / n_eff, plain[0].values, rtol=2e-6, atol=2e-6)
     with pytest.raises(ValueError):
         eng.set_mcmc_segments(65)
+
+
+def test_full_size_mcmc_calls_are_time_segmented_by_default(integrator):
+    """The default (MCX_SEGMENTS_AUTO): a launch of >= 1 048 576 chains -- two or more rounds of the chip's wave slots, C4's
+    size -- runs as 8 segments x 2 chain halves, smaller ones as one launch; set_mcmc_segments(0) turns it off. Same chains
+    either way: identical accepted-step counts (every accept decision), sums equal up to the regrouping of the f32 blocks."""
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo import runtime as rt
+
+    target = Distribution.from_pdf(lambda x: 0.5 * (np.exp(-0.5 * (x - 2) ** 2) + np.exp(-0.5 * (x + 2) ** 2)), support=(-10, 10))
+    proposal = Distribution.normal(0.0, 2.0)
+    f2 = [lambda x: x, lambda x: x * x]
+    eng = integrator._engine
+    auto = integrator.integrate_mcmc(f2, target, proposal, n_steps=301, n_chains=1_048_576, n_burnin=40, seed=5)
+    assert (auto.meta["segments"], auto.meta["launches"]) == (8, 16)
+    assert auto.meta["n_blocks"] * auto.meta["block"] == 1_048_576          # the workgroups of one segment, both halves
+    small = integrator.integrate_mcmc(f2, target, proposal, n_steps=301, n_chains=524_288, n_burnin=40, seed=5)
+    assert (small.meta["segments"], small.meta["launches"]) == (0, 1)
+    eng.set_mcmc_segments(0)
+    try:
+        one = integrator.integrate_mcmc(f2, target, proposal, n_steps=301, n_chains=1_048_576, n_burnin=40, seed=5)
+    finally:
+        eng.set_mcmc_segments(rt.SEGMENTS_AUTO)
+    assert (one.meta["segments"], one.meta["launches"]) == (0, 1)
+    assert one.meta["accept_rate"] == auto.meta["accept_rate"]
+    assert np.allclose(one.values, auto.values, rtol=2e-6, atol=2e-6), (one.values, auto.values)
+
+
+def test_segmented_mcmc_calls_in_flight_on_two_streams_keep_their_own_state(integrator):
+    """the side stream, its fork / join events and the {x, w} buffer of a time-segmented call used to be one
+    per ENGINE, so two segmented calls in flight on different streams of one engine resumed from each other's chain
+    state. They are kept per caller stream now (like the per-workgroup partial sums): two such calls, different seeds,
+    queued on two torch streams at once, each reproduce their own unsegmented result -- accept counts exactly."""
+    import torch
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo import runtime as rt
+
+    target = Distribution.from_pdf(lambda x: 0.5 * (np.exp(-0.5 * (x - 2) ** 2) + np.exp(-0.5 * (x + 2) ** 2)), support=(-10, 10))
+    proposal = Distribution.normal(0.0, 2.0)
+    f2 = [lambda x: x, lambda x: x * x]
+    eng = integrator._engine
+    prep = integrator.prepare_mcmc(f2, target, proposal)
+    sizes = (3000, 131_072, 500)                                   # ~0.5 ms per call: long enough to overlap
+    want = torch.zeros(2, prep.rows, dtype=torch.float64, device="cuda")
+    eng.set_mcmc_segments(0)
+    try:
+        for i, seed in enumerate((21, 22)):
+            n_eff = prep.launch(*sizes, seed, want[i])
+        torch.cuda.synchronize()
+        assert eng.last_launch()["launches"] == 1
+        eng.set_mcmc_segments(6)
+        got = torch.zeros(4, 2, prep.rows, dtype=torch.float64, device="cuda")
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for rep in range(4):                                       # keep both streams busy with alternating seeds
+            for i, seed in enumerate((21, 22)):
+                with torch.cuda.stream(streams[i]):
+                    prep.launch(*sizes, seed, got[rep, i])
+        assert eng.last_launch()["launches"] == 12 and eng.last_launch()["segments"] == 6
+        torch.cuda.synchronize()
+    finally:
+        eng.set_mcmc_segments(rt.SEGMENTS_AUTO)
+    w, g = want.cpu().numpy(), got.cpu().numpy()
+    for rep in range(4):
+        assert np.array_equal(g[rep, :, 2], w[:, 2]), (rep, g[rep, :, 2], w[:, 2])       # accepted steps: the same chains
+        assert np.allclose(g[rep, :, :2] / n_eff, w[:, :2] / n_eff, rtol=2e-6, atol=2e-6)
+    assert not np.array_equal(w[0], w[1])

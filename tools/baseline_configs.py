@@ -14,21 +14,44 @@ import math
 
 import numpy as np
 
-# Algorithmic VALU cost per unit (sample or MH step) in lane-op equivalents with the survey's weights (SURVEY.md 8d:
-# plain op 1, integer multiply 4, transcendental 2). "Algorithmic" = what the kernel's algorithm needs, not what the
-# compiler emitted; the executed instruction counts (SQ_INSTS_VALU per unit) are in profiles/r02_pmc_summary.txt.
-#   hash of one counter: state add 1 + lshr, add, lshr, xor, lshr, xor 6 + mul 4 = 11 (the Box-Muller angle word skips
-#   the last lshr/xor: 9); Box-Muller pair: cvt, guard max, log 2, fma, sqrt 2, angle bits 1, cos 2, sin 2, 2 mul = 14
-#   C2  per sample (11 + 9 + 14) / 2 = 17 ... counted as 19.5 in round 1 with u2 = cvt * 2^-32 instead of the bit trick;
-#       kept at 19.5 for comparability, + 3 mul + 4 add for x..x^4                                      -> 26.5
-#   C3  sampler 19.5 + affine 1 + cell lookup of p (fma, med3, cvt, address, fma) 5 + 1/q from the deviate
-#       (z*z, scale, exp2 2, * sigma sqrt(2 pi), * p) 6 + 3 mul for the powers + 4 weighted accumulates  -> 38.5
-#   C4  per MH step: proposal hashes (11 + 9) / 2 + accept hash 11 = 21; half a Box-Muller pair 7; affine 1; cell
-#       lookup 5; w = log p + z^2/2 2; log alpha 1; accept test (cvt, log 2, fma, cmp) 5; 2 state selects; x^2 and two
-#       accumulates 3                                                                                  -> 47
-#   C5  hash 11 + u (cvt, scale) 2 + inverse-CDF lookup (bucket 2, window unpack 2, ~2 search steps x 5, cell
-#       arithmetic 4) 18 + 32 powers by Newton pairs at 3 ops per power per pair = 48 + pair set-up 1.5   -> 80.5
-OPS_PER_UNIT = {"c1": 24.5, "c2": 26.5, "c3": 38.5, "c4": 47.0, "c5": 80.5}
+# VALU cost per unit (sample or MH step) in lane-op equivalents with the survey's weights (plain op 1 -- an
+# FMA is one op --, integer multiply 4, transcendental 2), counted on the ALGORITHM THE SHIPPED KERNEL RUNS: the hot loop of
+# the cached code object, disassembled and classified by tools/issue_model.py -> profiles/rNN_issue_model.json
+# (`survey_weighted_ops_per_unit`, keyed by the module's cache key). The constants below are that file's figures for the
+# round-3 kernels, used when the file is absent; ops_per_unit() prefers the file and says which it used.
+#   C2  per Box-Muller pair: state add, 2 hashes (8 + 6 instructions, one v_mul_lo each), cvt, guard max, log, fma, sqrt,
+#       alignbit, cos, sin, 2 mul = 24 instructions -> 18 plain + 2 x 4 + 4 x 2 = 34; per sample x, x^2, x^3, x^4 accumulate in
+#       5 (add, fma, mul, fma, fma) -> 17 + 5                                                                  = 22.0
+#   C3  C2's sampler + affine fma + cell lookup of p (fma, cvt, and, ds_read, fma) + 1/q from the deviate (mul, mul, exp,
+#       mul, mul) + weighted accumulation (3 mul + 4 fma)                                                      = 35.0
+#   C4  per MH step: half a pair's proposal (hash 8 + 6, Box-Muller 10, affine 2) / 2, accept hash 8, cell lookup 5,
+#       w = fma(z/2, z, lp), log alpha, accept test (cvt, log, fma, cmp), 2 state selects, x^2 + 2 accumulates  = 44.5
+#   C5  per sample: hash 8, bucket-direct read + flag compare + line fma 5, ring exchange 4, 32 powers by quads at 1.25 per
+#       power = 40, quad set-up 9 / 4, resolve of flagged draws 0.17 / 64 per sample                           = 63.1
+OPS_PER_UNIT = {"c1": 20.0, "c2": 22.0, "c3": 35.0, "c4": 44.5, "c5": 63.1}
+NOMINAL_CLOCK_GHZ = 2.4
+
+
+def ops_per_unit(name: str, module_key=None):
+    """(lane-op equivalents per unit, where the figure comes from). Prefers profiles/rNN_issue_model.json (latest round): the
+    entry of this very code object when module_key is given and known there, else the config's reference-stream entry."""
+    import json
+    from pathlib import Path
+
+    hits = sorted((Path(__file__).resolve().parent.parent / "profiles").glob("r[0-9][0-9]_issue_model.json"))
+    if hits:
+        try:
+            modules = json.loads(hits[-1].read_text()).get("modules", {})
+        except ValueError:
+            modules = {}
+        if module_key in modules:
+            return float(modules[module_key]["survey_weighted_ops_per_unit"]), f"profiles/{hits[-1].name}: this code object ({module_key})"
+        if module_key is None:
+            for entry in modules.values():
+                if entry.get("config") == name and entry.get("rng") == "pcg_ref":
+                    return float(entry["survey_weighted_ops_per_unit"]), f"profiles/{hits[-1].name}: config {name}, reference stream"
+    return OPS_PER_UNIT[name], "tools/baseline_configs.py OPS_PER_UNIT (hand count of the round-3 kernel; this code object is not in profiles/*_issue_model.json)"
+
 
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9      # 7.86e13: CUs x SIMDs x lanes x clock (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0

@@ -5,9 +5,9 @@
 #     8 SQ slots per pass; FETCH_SIZE and WRITE_SIZE cannot share a pass).
 # The program is placed directly after `--` (no env / bash -c hop: the profiler has initialised the GPU already), and
 # bench.py itself starts no child process under the profiler (--no-cold is implied there, given explicitly anyway).
-#   bash tools/profile_all.sh r02 [c2,c3,c4,c5]
+#   bash tools/profile_all.sh r03 [c2,c3,c4,c5]
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 CONFIGS=${2:-c2,c3,c4,c5}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"

@@ -15,6 +15,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "wgpu-monte-carlo_amd"))
 from wgpu_montecarlo import Distribution, MonteCarloIntegrator  # noqa: E402
+from wgpu_montecarlo import runtime as rt  # noqa: E402
 
 
 def rss_mb():
@@ -105,7 +106,7 @@ def main():
             try:
                 r = plain.integrate_mcmc(fns[:2], tgt, Distribution.normal(0.2, 1.7), **kw)
             finally:
-                plain._engine.set_mcmc_segments(0)
+                plain._engine.set_mcmc_segments(rt.SEGMENTS_AUTO)
             assert r.meta["accept_rate"] == one.meta["accept_rate"], (kw, r.meta["accept_rate"], one.meta["accept_rate"])
             assert np.allclose(r.values, one.values, rtol=5e-6, atol=5e-6), (kw, r.values, one.values)
         elif kind == 10:

@@ -64,6 +64,7 @@ const HipApi* hip_api(const char** why) {
                bind(lib, "hipModuleLaunchKernel", &a.ModuleLaunchKernel, &w) &&
                bind(lib, "hipFuncGetAttribute", &a.FuncGetAttribute, &w) && bind(lib, "hipStreamWaitEvent", &a.StreamWaitEvent, &w) &&
                bind(lib, "hipEventCreateWithFlags", &a.EventCreateWithFlags, &w);
+        a.HostGetDevicePointer = reinterpret_cast<decltype(a.HostGetDevicePointer)>(dlsym(lib, "hipHostGetDevicePointer"));
         a.library = name.c_str();
       } catch (...) { g_ok = false; g_why = "exception while binding the HIP runtime"; }
     });

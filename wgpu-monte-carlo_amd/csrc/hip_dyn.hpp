@@ -41,6 +41,7 @@ struct HipApi {
     hipError_t (*FuncGetAttribute)(int*, hipFunction_attribute, hipFunction_t);
     hipError_t (*StreamWaitEvent)(hipStream_t, hipEvent_t, unsigned int);
     hipError_t (*EventCreateWithFlags)(hipEvent_t*, unsigned int);
+    hipError_t (*HostGetDevicePointer)(void**, void*, unsigned int);  // optional (null if the runtime lacks it)
     const char* library;      // path or soname of the runtime that was bound
 };
 

@@ -60,6 +60,26 @@ def _check_count(value, name: str, bits: int = 64) -> int:
     return int(value)
 
 
+def _function_key(fn):
+    """Hashable identity of one integrand for the plan cache: frontend.fingerprint for callables (code object + every
+    captured value), the text itself for WGSL strings."""
+    if isinstance(fn, str):
+        return fn
+    return frontend.fingerprint(fn)
+
+
+def _distribution_key(d: Distribution):
+    """Identity of a Distribution for the plan cache. The cache entry keeps the object alive, so id() cannot be reused
+    while the entry exists; parameters and the identities of its closure / tables are part of the key, so replacing any
+    of them is seen. (Writing into a table array IN PLACE after it has been used is not: tables are treated as
+    immutable once a call has seen them -- build a new Distribution instead.)"""
+    p = d.params
+    return (id(d), d.dist_type, tuple(p.items()) if p else None, id(d._pdf_func), id(d._x_table), id(d._cdf_table),
+            id(d._pdf_table))
+
+
+_PLAN_CACHE_ENTRIES = 128
+
 _EMIT_CACHE = {}      # (code object | wgsl text, slot, math, captured constants) -> HIP text
 
 
@@ -250,9 +270,17 @@ class MonteCarloIntegrator:
             meta["tau_int"] and meta["ess"] (K <= 16).
     """
 
+    @classmethod
+    def planner(cls, **kw) -> "MonteCarloIntegrator":
+        """An integrator that compiles but cannot launch (no GPU needed): prepare_integrate / prepare_importance_sampling /
+        prepare_mcmc analyse the tables and hiprtc-compile the module into the code-object cache exactly as a call on
+        a GPU would, so a deployment can warm its cache in a GPU-less build step. Same keyword arguments as the
+        constructor (device / devices / process_group excepted)."""
+        return cls(_host_engine=True, **kw)
+
     def __init__(self, target_threads: Optional[int] = None, device: Optional[int] = None, process_group=None,
                  math: str = "default", strict_reference_uniform: bool = False, rng: str = "pcg_ref",
-                 std_error: bool = False, devices: Optional[Sequence[int]] = None):
+                 std_error: bool = False, devices: Optional[Sequence[int]] = None, _host_engine: bool = False):
         runtime.load()                               # ImportError if libmcx.so has not been built
         if math not in ("default", "fast", "precise"):
             raise ValueError("math must be 'default', 'fast' or 'precise'")
@@ -267,11 +295,11 @@ class MonteCarloIntegrator:
             if process_group is not None:
                 raise ValueError("devices (one process driving several GPUs) and process_group (one process per GPU) are alternatives")
             device = devices[0]
-        if device is None:
+        if device is None and not _host_engine:
             device = _default_device()
         # RuntimeError("Failed to initialize GPU: ...") without a GPU. Engines are shared per device: building an
         # integrator per call (as the convenience functions do) costs no device initialisation after the first.
-        self._engine = runtime.Engine.shared(device)
+        self._engine = runtime.HostEngine() if _host_engine else runtime.Engine.shared(device)
         self._engines = [self._engine]
         self._comm = None
         if devices is not None and len(devices) > 1:
@@ -291,6 +319,31 @@ class MonteCarloIntegrator:
         self._precise_sampler = math == "precise"
         self._guard = not strict_reference_uniform
         self._group = distributed.resolve_group(process_group)
+        # what a plan depends on besides the functions and distributions (plans are cached per engine, shared by integrators)
+        self._mode = (math, self._guard, self._rng, self._std_error)
+
+    # ---- plan cache -------------------------------------------------------------------------------
+    def _cached_plan(self, kind: str, functions, dists, extra, build):
+        """The compiled plan of a repeat call: one dict lookup on (function fingerprints, distribution identities, mode)
+        instead of lowering, emission, desc fitting and module lookup (the reference re-transpiles and re-compiles per
+        call, src/engine.rs:325-331). Anything unhashable or outside the emitter's subset takes the uncached path, which
+        raises what it always raised."""
+        cache = getattr(self._engine, "_plans", None)
+        if cache is None:
+            return build()
+        try:
+            key = (kind, tuple([_function_key(f) for f in functions]), tuple([_distribution_key(d) for d in dists]),
+                   self._mode, extra)
+            hit = cache.get(key)
+        except (TypeError, TranspilerError, AttributeError):
+            return build()
+        if hit is not None:
+            return hit[0]
+        plan = build()
+        if len(cache) >= _PLAN_CACHE_ENTRIES:
+            cache.pop(next(iter(cache)))             # oldest entry (dicts keep insertion order)
+        cache[key] = (plan, tuple(functions), tuple(dists))      # the strong references keep the id()s in the key valid
+        return plan
 
     # ---- helpers ---------------------------------------------------------------------------------
     def _table(self, kind: int, keys: np.ndarray, values: np.ndarray) -> runtime.Table:
@@ -334,6 +387,26 @@ class MonteCarloIntegrator:
             # C3 0.662 -> 0.629 ms, C4 8.65 -> 8.51 ms (256: 0.666 / 8.50; profiles/r02b_flush_period_and_block_size_sweep.txt)
             desc.block = 512
         return desc
+
+    def _build_module(self, user_src: str, desc, *tables: Optional[runtime.Table], extra_bytes: int = 0):
+        """Build (or fetch) the module for `desc`, then hold the plan-time LDS decisions against the code object's REAL
+        static LDS (the launch checks it: csrc/mcx_runtime.cpp integrate_impl / mcmc_impl). _fit_tables decided with an
+        upper bound; should the real figure ever be larger, a default-on optimisation (staged tables, cell_noclamp,
+        cell_addr16) must fall back to the slower form, not turn a valid call into MCX_E_INVALID."""
+        mod = self._engine.module(user_src, desc)
+        if not desc.tables_lds:
+            return mod
+        need = sum(tb.lds_bytes for tb in tables if tb is not None) + (extra_bytes if desc.cell_noclamp else 0)
+        if desc.cdf_direct:
+            need += (mod.block // 64) * 128 * 4             # the per-wave queues of the bucket-direct sampler
+        total = need + mod.static_lds
+        if need and total > runtime.LDS_PER_CU:
+            desc.tables_lds, desc.cdf_direct, desc.cell_noclamp, desc.cell_addr16 = 0, 0, 0, 0
+            return self._engine.module(user_src, desc)
+        if desc.cell_addr16 and total > 65536:
+            desc.cell_addr16 = 0
+            return self._engine.module(user_src, desc)
+        return mod
 
     def _cell_pads(self, cell_tables: bool, code: int, p1: float, p2: float, cdf, *tables) -> Optional[int]:
         """desc.cell_noclamp: can every cell table of the call be padded over the sampler's range (then the lookup needs
@@ -383,6 +456,8 @@ class MonteCarloIntegrator:
         g = self._group
         if g is None or g.world < 2:
             sums, n_eff = call(None, None)
+            if n_eff:
+                return sums / float(n_eff), n_eff
             with np.errstate(divide="ignore", invalid="ignore"):      # n_samples = 0 -> 0/0 = NaN, like the reference
                 return sums / float(n_eff), n_eff
         if g.backend == "nccl":
@@ -448,7 +523,7 @@ class MonteCarloIntegrator:
                                  second_moments=self._std_error, unit_params=_unit_params(code, p1, p2),
                                  moment_family=self._use_moment_family(functions), cdf_direct=self._cdf_direct(cdf, k))
         self._fit_tables(desc, cdf)
-        return _Plan("integrate", self._engine.module(user_src, desc), desc, k, runtime.result_rows(desc), p1, p2,
+        return _Plan("integrate", self._build_module(user_src, desc, cdf), desc, k, runtime.result_rows(desc), p1, p2,
                      dict(cdf=cdf))
 
     def _plan_importance_sampling(self, functions, target_distribution, proposal_distribution) -> _Plan:
@@ -485,15 +560,16 @@ class MonteCarloIntegrator:
                                  cell_tables=cells, q_sampler=q_sampler, cell_noclamp=pad_bytes is not None,
                                  moment_family=self._use_moment_family(functions), cdf_direct=self._cdf_direct(cdf, k))
         self._fit_tables(desc, cdf, p_table, q_table, extra_bytes=pad_bytes or 0)
-        return _Plan("integrate", self._engine.module(user_src, desc), desc, k, runtime.result_rows(desc), p1, p2,
-                     dict(cdf=cdf, target_pdf=p_table, proposal_pdf=q_table))
+        return _Plan("integrate", self._build_module(user_src, desc, cdf, p_table, q_table, extra_bytes=pad_bytes or 0), desc, k,
+                     runtime.result_rows(desc), p1, p2, dict(cdf=cdf, target_pdf=p_table, proposal_pdf=q_table))
 
-    def _mcmc_block(self, n_chains: int) -> int:
+    def _mcmc_block(self, n_chains: int, parts: Optional[int] = None) -> int:
         """desc.block for an MCMC call of n_chains chains: 0 (libmcx's default, 1024 threads when tables are staged)
         unless this rank's / device's share of the padded chains is too small to give every CU several workgroups of
         that size (mcx_mcmc_block_hint: 131 072 chains -- C4 over 8 GPUs -- run 1.5x faster with 256 threads)."""
         padded = runtime.mcmc_dispatch_config(n_chains, self._target_threads).total_threads
-        parts = len(self._engines) if len(self._engines) > 1 else self._rank_world()[1]
+        if parts is None:
+            parts = len(self._engines) if len(self._engines) > 1 else self._rank_world()[1]
         hint = runtime.mcmc_block_hint(-(-padded // max(parts, 1)))
         return 0 if hint >= 1024 else hint
 
@@ -536,7 +612,8 @@ class MonteCarloIntegrator:
                                  unit_params=_unit_params(code, p1, p2), second_moments=self._std_error, walk=walk,
                                  cell_tables=cells, q_sampler=q_sampler, cell_noclamp=pad_bytes is not None)
         self._fit_tables(desc, cdf, t_table, q_table, extra_bytes=pad_bytes or 0)
-        return _Plan("mcmc", self._engine.module(user_src, desc), desc, k, runtime.result_rows(desc), p1, p2,
+        return _Plan("mcmc", self._build_module(user_src, desc, cdf, t_table, q_table, extra_bytes=pad_bytes or 0), desc, k,
+                     runtime.result_rows(desc), p1, p2,
                      dict(cdf=cdf, target_logpdf=t_table, proposal_logpdf=q_table), x0=float(initial_state),
                      target_accept=float(target_accept), proposal_kind=proposal_kind, walk=walk)
 
@@ -558,7 +635,8 @@ class MonteCarloIntegrator:
     def integrate(self, functions: List[FunctionLike], distribution: Distribution, n_samples: int = 1_000_000,
                   seed: int = 42) -> IntegrationResult:
         """E[f_k(X)], X ~ distribution, for all functions on the same samples."""
-        plan = self._plan_integrate(functions, distribution)
+        plan = self._cached_plan("integrate", functions, (distribution,), None,
+                                 lambda: self._plan_integrate(functions, distribution))
         n_samples = _check_count(n_samples, "n_samples")
         seed = _check_seed(seed)
         values, n_eff = self._run(plan.rows, lambda d_sums, stream: self._enqueue(plan, n_samples, seed, d_sums, stream),
@@ -571,7 +649,8 @@ class MonteCarloIntegrator:
                                       proposal_distribution: Distribution, n_samples: int = 1_000_000,
                                       seed: int = 42) -> IntegrationResult:
         """E_p[f_k(X)] ~= mean f_k(x) p(x)/q(x), x ~ q."""
-        plan = self._plan_importance_sampling(functions, target_distribution, proposal_distribution)
+        plan = self._cached_plan("is", functions, (target_distribution, proposal_distribution), None,
+                                 lambda: self._plan_importance_sampling(functions, target_distribution, proposal_distribution))
         n_samples = _check_count(n_samples, "n_samples")
         seed = _check_seed(seed)
         values, n_eff = self._run(plan.rows, lambda d_sums, stream: self._enqueue(plan, n_samples, seed, d_sums, stream),
@@ -603,8 +682,11 @@ class MonteCarloIntegrator:
             raise ValueError("At least one function is required")
         n_steps, n_chains, n_burnin = self._check_mcmc_sizes(n_steps, n_chains, n_burnin)
         seed = _check_seed(seed)
-        plan = self._plan_mcmc(functions, target_distribution, proposal_distribution, proposal_kind, initial_state,
-                               target_accept, block=self._mcmc_block(n_chains))
+        block = self._mcmc_block(n_chains)
+        plan = self._cached_plan("mcmc", functions, (target_distribution, proposal_distribution),
+                                 (proposal_kind, float(initial_state), float(target_accept), block),
+                                 lambda: self._plan_mcmc(functions, target_distribution, proposal_distribution, proposal_kind,
+                                                         initial_state, target_accept, block=block))
         values, n_eff = self._run(plan.rows, lambda d_sums, stream: self._enqueue(
             plan, (n_steps, n_chains, n_burnin), seed, d_sums, stream), plan, (n_steps, n_chains, n_burnin), seed)
         return self._mcmc_result(plan, values, n_eff, n_steps, n_chains, n_burnin)
@@ -668,12 +750,11 @@ class MonteCarloIntegrator:
         return PreparedMcmc(self, make(0), make)
 
     def _meta(self, n_eff: int, values=None, k: int = 0) -> dict:
-        launch = self._engine.last_launch()
+        meta = self._engine.last_call()               # n_blocks, block, lds_bytes, launches, kernel_ms: one C call
         rank, world = self._rank_world()
-        meta = dict(n_eff=n_eff, kernel_ms=self._engine.last_kernel_ms(), n_blocks=launch["n_blocks"],
-                    block=launch["block"], lds_bytes=launch["lds_bytes"], rank=rank, world=world,
-                    devices=[e.device for e in self._engines],
-                    collective=("rccl" if self._comm is not None else "host-sum") if len(self._engines) > 1 else None)
+        meta["n_eff"], meta["rank"], meta["world"] = n_eff, rank, world
+        meta["devices"] = [e.device for e in self._engines]
+        meta["collective"] = ("rccl" if self._comm is not None else "host-sum") if len(self._engines) > 1 else None
         if values is not None and len(values) == 2 * k and k:
             with np.errstate(invalid="ignore", divide="ignore"):
                 var = np.maximum(values[k:] - values[:k] ** 2, 0.0)
@@ -689,7 +770,7 @@ class PreparedIntegrand:
         self._owner, self._plan = owner, plan
         self.k, self.rows = plan.k, plan.rows
 
-    def _launch(self, sizes, seed: int, out, async_op: bool, reduce: bool):
+    def _launch(self, sizes, seed: int, out, async_op: bool, reduce: bool, shard=None):
         import torch
 
         owner = self._owner
@@ -699,21 +780,25 @@ class PreparedIntegrand:
         if out.dtype != torch.float64 or out.numel() < self.rows or not out.is_contiguous():
             raise ValueError(f"out must be a contiguous float64 CUDA tensor with at least {self.rows} elements")
         stream = torch.cuda.current_stream(out.device).cuda_stream
-        _, n_eff = owner._enqueue(self._plan, sizes, seed, out.data_ptr(), stream)
+        _, n_eff = owner._enqueue(self._plan, sizes, seed, out.data_ptr(), stream, rank_world=shard)
         work = None
-        if reduce and owner._rank_world()[1] > 1:
+        if reduce and shard is None and owner._rank_world()[1] > 1:
             work = distributed.all_reduce_device(owner._group, out, async_op=async_op)
         return (n_eff, work) if async_op else n_eff
 
-    def launch(self, n_samples: int, seed: int, out, async_op: bool = False, reduce: bool = True):
+    def launch(self, n_samples: int, seed: int, out, async_op: bool = False, reduce: bool = True, shard=None):
         """Enqueue sampling + reduction (+ one sum all-reduce when sharded) on torch's current stream.
+
+        shard=(rank, world) overrides the integrator's own position in its process group for this launch and implies
+        reduce=False: (0, 1) runs the WHOLE grid on this GPU -- what bench.py's sharded-equals-single check compares
+        the all-reduced shards with.
 
         `out` is a float64 CUDA tensor with `rows` (= k; 2k with std_error) elements that receives the SUMS over the
         whole job (all ranks); divide by the returned n_eff for the expected values. No host synchronisation.
         With async_op=True the collective does not block the current stream (the next launch overlaps it);
         returns (n_eff, work) and the caller waits on `work` (None on a single GPU) before reading `out`.
         reduce=False leaves this rank's partial sums in `out` (no collective)."""
-        return self._launch(int(n_samples), seed, out, async_op, reduce)
+        return self._launch(int(n_samples), seed, out, async_op, reduce, shard)
 
     def run(self, n_samples: int, seed: int = 42) -> IntegrationResult:
         """Blocking form: same result as MonteCarloIntegrator.integrate() / integrate_importance_sampling()."""
@@ -734,19 +819,19 @@ class PreparedMcmc(PreparedIntegrand):
         self._make_plan = make_plan
         self._variants = {0: plan}
 
-    def _select(self, n_chains: int) -> None:
-        block = self._owner._mcmc_block(n_chains)
+    def _select(self, n_chains: int, shard=None) -> None:
+        block = self._owner._mcmc_block(n_chains, parts=shard[1] if shard is not None else None)
         if block not in self._variants:
             self._variants[block] = self._make_plan(block)
         self._plan = self._variants[block]
 
     def launch(self, n_steps: int, n_chains: int, n_burnin: int, seed: int, out, async_op: bool = False,
-               reduce: bool = True):
+               reduce: bool = True, shard=None):
         """Enqueue this rank's chains (+ one sum all-reduce when sharded); `out` receives `rows` sums, n_eff =
         padded chains x n_steps is returned. See PreparedIntegrand.launch."""
         sizes = MonteCarloIntegrator._check_mcmc_sizes(n_steps, n_chains, n_burnin)
-        self._select(sizes[1])
-        return self._launch(sizes, seed, out, async_op, reduce)
+        self._select(sizes[1], shard)
+        return self._launch(sizes, seed, out, async_op, reduce, shard)
 
     def run(self, n_steps: int = 10_000, n_chains: int = 1024, n_burnin: int = 1_000, seed: int = 42) -> IntegrationResult:
         """Blocking form: same result as MonteCarloIntegrator.integrate_mcmc()."""

@@ -576,6 +576,36 @@ def lower(func: Callable, bind_defaults: bool = False) -> Function:
     return Function(rec.name, params, consts, rec.body)
 
 
+_FINGERPRINT_NAMES: Dict[object, tuple] = {}      # code object -> global names whose values the function reads
+
+
+def fingerprint(func: Callable, bind_defaults: bool = True) -> tuple:
+    """A hashable key that is equal for two callables exactly when lower() gives them the same IR and the same
+    captured constants: (code object, closure values, defaults, values of the globals it reads). A repeat call with
+    the same function then costs one dict lookup instead of a lowering + emission (the reference re-transpiles on
+    every call, python/wgpu_montecarlo/__init__.py:740-746). Raises TranspilerError like lower(); TypeError when a
+    captured value is not hashable (lower() rejects those too)."""
+    code = getattr(func, "__code__", None)
+    if code is None:
+        raise TranspilerError(f"Could not get source code: {type(func).__name__} is not a Python function")
+    names = _FINGERPRINT_NAMES.get(code)
+    if names is None:
+        lower(func, bind_defaults)                              # structural checks + fills _LOWER_CACHE
+        rec = _LOWER_CACHE[code]
+        skip = set(rec.params) | rec.assigned | set(rec.imports) | set(rec.module_aliases) | _EXCLUDED_AS_BUILTINS
+        names = tuple(sorted(n for n in rec.used - skip if n not in code.co_freevars))
+        if len(_FINGERPRINT_NAMES) >= _LOWER_CACHE_LIMIT:
+            _FINGERPRINT_NAMES.clear()
+        _FINGERPRINT_NAMES[code] = names
+    cells = func.__closure__
+    g = func.__globals__
+    try:
+        return (code, tuple(c.cell_contents for c in cells) if cells else None, func.__defaults__,
+                tuple(g.get(n) for n in names) if names else None)
+    except ValueError:                                          # an empty closure cell
+        raise TypeError("closure cell is empty")
+
+
 def _lower_structure(func: Callable) -> _Lowered:
     is_lambda = func.__name__ == "<lambda>"
     if is_lambda:

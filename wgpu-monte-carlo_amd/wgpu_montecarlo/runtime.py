@@ -73,6 +73,11 @@ class TableFacts(C.Structure):
                 ("value_max", C.c_float), ("reach_known", C.c_uint32)]
 
 
+class CallInfo(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_blocks", C.c_uint32), ("block", C.c_uint32), ("lds_bytes", C.c_uint32),
+                ("launches", C.c_uint32), ("kernel_ms", C.c_float), ("segments", C.c_uint32)]
+
+
 _SZ_INTEGRATE, _SZ_MCMC = C.sizeof(IntegrateParams), C.sizeof(McmcParams)
 SEGMENTS_AUTO = 0xFFFFFFFF
 ABI_VERSION = 3
@@ -88,7 +93,7 @@ EXPORTED_SYMBOLS = [
     "mcx_engine_last_launch_count", "mcx_module_static_lds", "mcx_lds_table_budget", "mcx_rccl_library",
     "mcx_comm_create", "mcx_comm_destroy", "mcx_comm_size", "mcx_integrate_comm", "mcx_mcmc_comm",
     "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct", "mcx_mcmc_block_hint", "mcx_cell_pads", "mcx_cell_pads_host", "mcx_default_launch_blocks", "mcx_engine_set_mcmc_segments",
-    "mcx_abi_version", "mcx_module_key", "mcx_table_analyse", "mcx_table_facts_of",
+    "mcx_abi_version", "mcx_module_key", "mcx_table_analyse", "mcx_table_facts_of", "mcx_engine_last_call", "mcx_module_block",
 ]
 
 _lib = None
@@ -215,6 +220,9 @@ def load():
         L.mcx_module_key.argtypes = [C.c_char_p, C.POINTER(ModuleDesc), C.c_char_p]
         L.mcx_table_analyse.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), u32, C.POINTER(TableFacts)]
         L.mcx_table_facts_of.argtypes = [vp, C.POINTER(TableFacts)]
+        L.mcx_engine_last_call.argtypes = [vp, C.POINTER(CallInfo), C.c_int]
+        L.mcx_module_block.argtypes = [vp]
+        L.mcx_module_block.restype = u32
         if int(L.mcx_abi_version()) != ABI_VERSION:
             raise ImportError(f"{LIB_PATH} has ABI version {L.mcx_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
         _lib = L
@@ -289,6 +297,11 @@ def make_desc(kind: int, k: int, dist_type: int, weight: bool = False, p_table: 
 def cell_pads(table: "Table", dist_type: int, p1: float, p2: float, cdf: Optional["Table"] = None, guard: bool = True):
     """(pad_l, pad_r): the sentinel cells a cell_noclamp launch adds either side of `table` when the call samples from
     (dist_type, p1, p2[, cdf]); None when the table has no cell form or the sampler's range is unbounded / too wide."""
+    if isinstance(table, HostTable):             # planning without a device: the same arithmetic from the keys alone
+        x_range = (cdf.value_min, cdf.value_max) if (cdf is not None and cdf.reach_known) else None
+        if dist_type == DIST_CUSTOM and x_range is None:
+            return None
+        return cell_pads_host(table.keys, dist_type, p1, p2, x_range, guard) if table.has_cells else None
     pl, pr = C.c_uint32(), C.c_uint32()
     ok = load().mcx_cell_pads(table._h, int(dist_type), float(p1), float(p2), cdf._h if cdf is not None else None, int(guard),
                               C.byref(pl), C.byref(pr))
@@ -424,9 +437,13 @@ class Table:
                                       len(keys), C.byref(self._h)))
         self.kind, self.n = kind, len(keys)
         self.keys, self.values = keys, values                              # kept: the table is re-created per device
-        self.has_cells = int(load().mcx_table_has_cells(self._h)) == 1     # slope-intercept cell form (strict grid)
-        self.direct_bits = int(load().mcx_table_has_direct(self._h))       # CDF tables: bucket-direct records (0: none)
-        self.lds_bytes = int(load().mcx_table_lds_bytes(self._h))          # staged per workgroup when tables_lds = 1
+        f = TableFacts(C.sizeof(TableFacts))
+        check(load().mcx_table_facts_of(self._h, C.byref(f)))
+        self.has_cells = f.has_cells == 1                # slope-intercept cell form (strict grid)
+        self.direct_bits = int(f.direct_bits)            # CDF tables: bucket-direct records (0: none)
+        self.lds_bytes = int(f.lds_bytes)                # staged per workgroup when tables_lds = 1
+        self.reach_known = f.reach_known == 1            # CDF tables: every draw stays inside [value_min, value_max]
+        self.value_min, self.value_max = float(f.value_min), float(f.value_max)
 
     def info(self) -> dict:
         n, inv, bits = C.c_uint32(), C.c_float(), C.c_uint32()
@@ -453,6 +470,7 @@ class Module:
         self._h = C.c_void_p()
         check(load().mcx_module_build(engine._h, user_src.encode(), C.byref(desc), C.byref(self._h)))
         self.static_lds = int(load().mcx_module_static_lds(self._h))
+        self.block = int(load().mcx_module_block(self._h))
 
     def release(self) -> None:
         if self._h:
@@ -464,6 +482,60 @@ class Module:
             self.release()
         except Exception:
             pass
+
+
+class HostTable:
+    """What a planner needs to know about a table, derived without a device (include/mcx.h: mcx_table_analyse)."""
+
+    _h = None
+
+    def __init__(self, kind: int, keys: np.ndarray, values: np.ndarray):
+        keys = np.ascontiguousarray(keys, dtype=np.float32)
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        if keys.shape != values.shape or keys.ndim != 1:
+            raise ValueError("table keys and values must be 1D arrays of the same length")
+        f = table_facts(kind, keys, values)
+        self.kind, self.n, self.keys, self.values = kind, len(keys), keys, values
+        self.has_cells, self.direct_bits, self.lds_bytes = f.has_cells == 1, int(f.direct_bits), int(f.lds_bytes)
+        self.reach_known = f.reach_known == 1
+        self.value_min, self.value_max = float(f.value_min), float(f.value_max)
+
+
+class HostModule:
+    """A module that exists as a cached code object only (hiprtc needs no GPU): what HostEngine.module returns."""
+
+    _h = None
+
+    def __init__(self, user_src: str, desc: ModuleDesc):
+        self.user_src, self.desc = user_src, desc
+        self.cache_hit = precompile(user_src, desc)              # 0 = compiled now, 1 / 2 = memory / disk hit
+        self.key = module_key(user_src, desc)
+        self.static_lds = LDS_PER_CU - lds_table_budget(desc)    # the upper bound the planner works with
+        self.block = int(desc.block)
+
+    @property
+    def code_object(self) -> Path:
+        return Path(cache_dir()) / f"{self.key}.hsaco"
+
+
+class HostEngine:
+    """Compile-only stand-in for Engine: tables are analysed and modules compiled into the code-object cache exactly as
+    a call on a GPU would build them, but nothing can be launched. For warming a deployment's cache in a GPU-less
+    build step (__graft_entry__.build) and for inspecting what a call compiles to (tools/issue_model.py)."""
+
+    device = -1
+    _h = None
+
+    def cached_table(self, kind: int, keys, values) -> HostTable:
+        return HostTable(kind, keys, values)
+
+    def module(self, user_src: str, desc: ModuleDesc) -> HostModule:
+        return HostModule(user_src, desc)
+
+    def _no_gpu(self, *a, **k):
+        raise RuntimeError("this integrator was built with MonteCarloIntegrator.planner(): it compiles, it cannot launch")
+
+    integrate = mcmc = last_call = last_launch = last_kernel_ms = set_target_threads = set_mcmc_segments = _no_gpu
 
 
 class Engine:
@@ -478,6 +550,7 @@ class Engine:
         self.device = int(device)
         self._modules = {}
         self._tables = {}
+        self._plans = {}               # api._cached_plan: compiled plans of repeat calls (hold modules + tables)
         _live_engines.add(self)        # closed at interpreter exit while the HIP runtime is still fully alive
 
     @classmethod
@@ -568,11 +641,18 @@ class Engine:
     def last_kernel_ms(self) -> float:
         return float(load().mcx_engine_last_kernel_ms(self._h))
 
+    def last_call(self, with_timing: bool = True) -> dict:
+        """Launch geometry and main-kernel time of the last call, one C call (include/mcx.h: mcx_engine_last_call)."""
+        info = CallInfo(C.sizeof(CallInfo))
+        check(load().mcx_engine_last_call(self._h, C.byref(info), int(with_timing)))
+        d = dict(n_blocks=info.n_blocks, block=info.block, lds_bytes=info.lds_bytes, launches=info.launches,
+                 segments=info.segments)
+        if with_timing:
+            d["kernel_ms"] = float(info.kernel_ms)
+        return d
+
     def last_launch(self) -> dict:
-        nb, b, lds = C.c_uint32(), C.c_uint32(), C.c_uint32()
-        check(load().mcx_engine_last_launch(self._h, C.byref(nb), C.byref(b), C.byref(lds)))
-        return dict(n_blocks=nb.value, block=b.value, lds_bytes=lds.value,
-                    launches=int(load().mcx_engine_last_launch_count(self._h)))
+        return self.last_call(with_timing=False)      # no wait: the geometry is known when the call is enqueued
 
     @staticmethod
     def _ptr(t: Optional[Table]):
@@ -619,6 +699,7 @@ class Engine:
         for comm in list(_live_comms):      # a communicator over this engine goes first
             if any(e is self for e in comm._engines):
                 comm.close()
+        self._plans.clear()
         for mod in list(self._modules.values()):
             mod.release()
         self._modules.clear()
