@@ -1206,7 +1206,7 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 // stage 2: fold partials[n_blocks][rows] -> out[rows] in a fixed order (one workgroup per row)
 // =============================================================================================
 extern "C" __global__ void __launch_bounds__(256)
-mcx_fold_kernel(const double* partials, u32 n_blocks, double* out) {
+mcx_fold_kernel(const double* partials, u32 n_blocks, double* out, u32* done, u32 ticket) {
     __shared__ double red[4];
     const u32 rows = gridDim.x;
     double s = 0.0;
@@ -1214,5 +1214,13 @@ mcx_fold_kernel(const double* partials, u32 n_blocks, double* out) {
     s = mcx_wave_sum(s);
     if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0u) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0u) {
+        out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        // Blocking calls: `out` and `done` are pinned host memory. The row's ticket is stored after its sum, ordered by a
+        // system-scope fence; the host polls the `rows` tickets instead of waiting for the stream's completion signal.
+        if (done != nullptr) {
+            __threadfence_system();
+            __hip_atomic_store(&done[blockIdx.x], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }

@@ -80,6 +80,20 @@ def _distribution_key(d: Distribution):
 
 _PLAN_CACHE_ENTRIES = 128
 
+# Tuning knobs read while a plan is built (here, in runtime.make_desc and in libmcx's source assembly): part of the plan
+# key, so flipping one at run time (A/B scripts, tests) is not answered from the cache.
+_PLAN_ENV = ("MCX_BLOCK", "MCX_NO_ADDR16", "MCX_NO_NOCLAMP", "MCX_DIRECT_MAX_ROWS", "MCX_NO_DIRECT", "MCX_NO_CELLS",
+             "MCX_EXTRA_DEFINES", "MCX_EXTRA_FLAGS")
+_ENV_DATA = getattr(os.environ, "_data", None)            # CPython on POSIX: the bytes-keyed dict behind os.environ
+_PLAN_ENV_B = tuple(os.fsencode(k) for k in _PLAN_ENV)
+
+
+def _env_key():
+    d = _ENV_DATA
+    if d is not None:
+        return tuple([d.get(k) for k in _PLAN_ENV_B])       # ~0.4 us; os.environ.get would encode every name
+    return tuple([os.environ.get(k) for k in _PLAN_ENV])
+
 _EMIT_CACHE = {}      # (code object | wgsl text, slot, math, captured constants) -> HIP text
 
 
@@ -333,7 +347,7 @@ class MonteCarloIntegrator:
             return build()
         try:
             key = (kind, tuple([_function_key(f) for f in functions]), tuple([_distribution_key(d) for d in dists]),
-                   self._mode, extra)
+                   self._mode, extra, _env_key())
             hit = cache.get(key)
         except (TypeError, TranspilerError, AttributeError):
             return build()

@@ -526,6 +526,9 @@ class HostEngine:
     device = -1
     _h = None
 
+    def __init__(self):
+        self._plans = {}               # api._cached_plan
+
     def cached_table(self, kind: int, keys, values) -> HostTable:
         return HostTable(kind, keys, values)
 
