@@ -448,8 +448,14 @@ def test_large_tables_and_capped_search(integrator, n_prop, n_tgt, in_lds):
     t_tab = integrator._table(rt.TABLE_PDF, target._x_table, target._pdf_table)
     q_tab = integrator._table(rt.TABLE_PDF, *proposal.get_or_compute_pdf_table())
     cdf = integrator._cdf_table(proposal)
-    pads = 8 * sum(sum(rt.cell_pads(t, rt.DIST_CUSTOM, 0.0, 0.0, cdf)) for t in (t_tab, q_tab))
-    assert pads > 8 * 4
+    if n_prop <= 4096:
+        pads = 8 * sum(sum(rt.cell_pads(t, rt.DIST_CUSTOM, 0.0, 0.0, cdf)) for t in (t_tab, q_tab))
+        assert pads > 8 * 4 and cdf.reach_known
+    else:
+        # no guide / bucket-direct form beyond 4096 points: the capped search can stop short of the cell that holds u, so
+        # the draws are not provably inside the x column -- the lookups keep their index clamp
+        assert not cdf.reach_known and all(rt.cell_pads(t, rt.DIST_CUSTOM, 0.0, 0.0, cdf) is None for t in (t_tab, q_tab))
+        pads = 0
     assert res.meta["lds_bytes"] == ((bare + pads if bare + pads <= 80 * 1024 else bare) if in_lds else 0)
     ref = oracle.integrate([(oracle.FN_IDENTITY, 0), (oracle.FN_POW, 2)], oracle.CUSTOM, n_samples=1_000_000, seed=4, guard=1,
                            cdf_table=proposal._cdf_table, x_table=proposal._x_table,

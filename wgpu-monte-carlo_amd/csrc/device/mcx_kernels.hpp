@@ -188,7 +188,18 @@ MCX_DEV McxCdfDirect mcx_stage_cdf_direct(const McxTableDesc& d, u32& off) {
     cd.slopes = d.slopes;
     __attribute__((address_space(3))) float2* dst = (__attribute__((address_space(3))) float2*)(mcx_lds_raw + off);
     const u32 dn = 1u << d.direct_bits;
+#if MCX_DIRECT_SOA
+    // experiment (profiles/r03_c5_lds_variants.txt): the records as two 4-byte planes {x_b}[G], {slope}[G] instead of 8-byte pairs
+    __attribute__((address_space(3))) float* px = (__attribute__((address_space(3))) float*)dst;
+    for (u32 i = threadIdx.x; i < dn; i += MCX_BLOCK) {
+        const float2 r = ((const float2*)d.direct)[i];
+        px[i] = r.x;
+        px[dn + i] = r.y;
+    }
+    cd.plane = dn;
+#else
     for (u32 i = threadIdx.x; i < dn; i += MCX_BLOCK) dst[i] = ((const float2*)d.direct)[i];
+#endif
     off += dn * 8u;
     cd.rec = dst;
     return cd;
@@ -382,6 +393,27 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
     __shared__ double wave_sums[MCX_WAVES][MCX_K];
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane < (u32)MCX_K) wave_sums[wave][lane] = 0.0;
+    // MCX_FLUSH_DPP (default): the K wave totals are formed by DPP adds on the vector ALU (mcx_wave_sum_f32_dpp: valid in
+    // lanes 48..63) instead of 6 ds_bpermute_b32 per row on the LDS pipe, lane 48 + k % 16 keeps row k's total, and the
+    // f64 slots in LDS are then updated by 16 lanes at once -- ceil(K / 16) read-modify-writes per flush instead of K
+    // dependent ones by lane 0 (K = 32: 192 bpermutes and a 32-deep chain of LDS round trips per wave per 512 samples).
+#ifndef MCX_FLUSH_DPP
+#define MCX_FLUSH_DPP 1
+#endif
+#if MCX_FLUSH_DPP
+    const u32 flush_rel = lane - 48u;             // 0..15 in the lanes that hold the totals, >= 2^32 - 48 elsewhere
+#define MCX_FLUSH_ACC()                                                                     \
+    do {                                                                                    \
+        float mine_[(MCX_K + 15) / 16];                                                     \
+        _Pragma("unroll") for (int g = 0; g < (MCX_K + 15) / 16; ++g) mine_[g] = 0.0f;     \
+        _Pragma("unroll") for (int k = 0; k < MCX_K; ++k) {                                 \
+            const float s_ = mcx_wave_sum_f32_dpp(MCX_PAIR_LANES ? MCX_ACC_A(k) + MCX_ACC_B(k) : MCX_ACC_A(k)); \
+            mine_[k / 16] = flush_rel == (u32)(k % 16) ? s_ : mine_[k / 16];                \
+        }                                                                                   \
+        _Pragma("unroll") for (int g = 0; g < (MCX_K + 15) / 16; ++g)                       \
+            if (flush_rel < 16u && 16u * g + flush_rel < (u32)MCX_K) wave_sums[wave][16u * g + flush_rel] += (double)mine_[g]; \
+    } while (0)
+#else
 #define MCX_FLUSH_ACC()                                                                     \
     do {                                                                                    \
         _Pragma("unroll") for (int k = 0; k < MCX_K; ++k) {                                 \
@@ -389,6 +421,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
             if (lane == 0u) wave_sums[wave][k] += (double)s_;                               \
         }                                                                                   \
     } while (0)
+#endif
 #else
     double sum[MCX_K];
 #pragma unroll
@@ -448,7 +481,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         __builtin_amdgcn_wave_barrier();
         if (lane_id < take) {
             const u32 h = queue[base + lane_id];
-            const float2 r = cd.rec[h >> cd.shift];
+            const float2 r = mcx_cdf_rec(cd, h);
             queue[base + lane_id] =
                 __builtin_bit_cast(u32, mcx_cdf_search_window(cd, __builtin_bit_cast(u32, r.x), (float)h * 0x1.0p-32f));
         }
@@ -467,7 +500,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         r_pos = np & 127u;
     };
     auto direct_one = [&](u32 h, float& x, bool& l) {
-        const float2 r = cd.rec[h >> cd.shift];
+        const float2 r = mcx_cdf_rec(cd, h);
         const u64 m = mcx_cdf_flag_mask(r);
         const bool f = mcx_inverse_ballot(m);
         x = mcx_cdf_line(cd, r, h);
@@ -475,8 +508,8 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         swap_in(m, f, h, x, l);
     };
     auto direct_pair = [&](u32 hA, u32 hB, float& xA, float& xB, bool& lA, bool& lB) {
-        const float2 rA = cd.rec[hA >> cd.shift];
-        const float2 rB = cd.rec[hB >> cd.shift];
+        const float2 rA = mcx_cdf_rec(cd, hA);
+        const float2 rB = mcx_cdf_rec(cd, hB);
         const u64 mA = mcx_cdf_flag_mask(rA), mB = mcx_cdf_flag_mask(rB);
         const bool fA = mcx_inverse_ballot(mA), fB = mcx_inverse_ballot(mB);
         xA = mcx_cdf_line(cd, rA, hA), xB = mcx_cdf_line(cd, rB, hB);
@@ -499,7 +532,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         __builtin_amdgcn_wave_barrier();
         if (lane_id < take) {
             const u32 h = queue[q_count - take + lane_id];
-            const float2 r = cd.rec[h >> cd.shift];
+            const float2 r = mcx_cdf_rec(cd, h);
             const float x = mcx_cdf_search_window(cd, __builtin_bit_cast(u32, r.x), (float)h * 0x1.0p-32f);
             mcx_accumulate<MCX_ACC_S>(x, is_tb, acc);
         }
@@ -520,7 +553,7 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
     };
     // a flagged lane sits the evaluation out (l = false; its x is ~1e-34, mcx_cdf_line); its draw is evaluated in resolve
     auto direct_one = [&](u32 h, float& x, bool& l) {
-        const float2 r = cd.rec[h >> cd.shift];
+        const float2 r = mcx_cdf_rec(cd, h);
         const u64 m = mcx_cdf_flag_mask(r);
         const bool f = mcx_inverse_ballot(m);
         x = mcx_cdf_line(cd, r, h);
@@ -528,8 +561,8 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
         defer(m, f, h);
     };
     auto direct_pair = [&](u32 hA, u32 hB, float& xA, float& xB, bool& lA, bool& lB) {
-        const float2 rA = cd.rec[hA >> cd.shift];
-        const float2 rB = cd.rec[hB >> cd.shift];
+        const float2 rA = mcx_cdf_rec(cd, hA);
+        const float2 rB = mcx_cdf_rec(cd, hB);
         const u64 mA = mcx_cdf_flag_mask(rA), mB = mcx_cdf_flag_mask(rB);
         const bool fA = mcx_inverse_ballot(mA), fB = mcx_inverse_ballot(mB);
         xA = mcx_cdf_line(cd, rA, hA), xB = mcx_cdf_line(cd, rB, hB);
