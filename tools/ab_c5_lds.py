@@ -3,8 +3,8 @@
 (round 2: SQ_WAIT_ANY / SQ_WAVE_CYCLES 0.39, LDS array 34 % busy, 46 % of those cycles bank conflicts).
 
 Variants (compile-time switches of device/mcx_kernels.hpp, handed to libmcx through MCX_EXTRA_DEFINES):
-  bpermute_flush   the round-2 wave flush: 6 ds_bpermute_b32 per row + 32 dependent LDS read-modify-writes by lane 0
-  dpp_flush        DPP row reductions on the vector ALU, 16 lanes update the f64 slots at once        (the new default)
+  bpermute_flush   the wave flush as shipped: 6 ds_bpermute_b32 per row + 32 dependent LDS read-modify-writes by lane 0
+  dpp_flush        DPP row reductions on the vector ALU, 16 lanes update the f64 slots at once
   dpp_soa_2xb32    + bucket-direct records as two 4-byte planes, two ds_read_b32 per draw
   dpp_soa_read2    + the same planes read by one ds_read2st64_b32
   dpp_flush512     + f32 accumulators folded every 512 units instead of 256
@@ -25,8 +25,8 @@ import tempfile
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-VARIANTS = [("bpermute_flush", "MCX_FLUSH_DPP=0"), ("dpp_flush", ""), ("dpp_soa_2xb32", "MCX_DIRECT_SOA=1"),
-            ("dpp_soa_read2", "MCX_DIRECT_SOA=2"), ("dpp_flush512", "MCX_FLUSH=512")]
+VARIANTS = [("bpermute_flush", "MCX_FLUSH_DPP=0"), ("dpp_flush", "MCX_FLUSH_DPP=1"), ("dpp_soa_2xb32", "MCX_FLUSH_DPP=1;MCX_DIRECT_SOA=1"),
+            ("dpp_soa_read2", "MCX_FLUSH_DPP=1;MCX_DIRECT_SOA=2"), ("dpp_flush512", "MCX_FLUSH_DPP=1;MCX_FLUSH=512")]
 BENCH = ["bench.py", "--config", "c5", "--no-cpu-baseline", "--no-cold", "--no-philox", "--legs", "none"]
 PASSES = [["SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_LDS",
            "SQ_BUSY_CYCLES"],

@@ -393,12 +393,15 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
     __shared__ double wave_sums[MCX_WAVES][MCX_K];
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane < (u32)MCX_K) wave_sums[wave][lane] = 0.0;
-    // MCX_FLUSH_DPP (default): the K wave totals are formed by DPP adds on the vector ALU (mcx_wave_sum_f32_dpp: valid in
-    // lanes 48..63) instead of 6 ds_bpermute_b32 per row on the LDS pipe, lane 48 + k % 16 keeps row k's total, and the
-    // f64 slots in LDS are then updated by 16 lanes at once -- ceil(K / 16) read-modify-writes per flush instead of K
-    // dependent ones by lane 0 (K = 32: 192 bpermutes and a 32-deep chain of LDS round trips per wave per 512 samples).
+    // MCX_FLUSH_DPP=1 (experiment, NOT the default): the K wave totals formed by DPP adds on the vector ALU
+    // (mcx_wave_sum_f32_dpp: valid in lanes 48..63) instead of 6 ds_bpermute_b32 per row on the LDS pipe, lane 48 + k % 16
+    // keeping row k's total and 16 lanes updating the f64 slots in LDS at once -- ceil(K / 16) read-modify-writes per
+    // flush instead of K dependent ones by lane 0. Measured on C5 (profiles/r03_c5_lds_variants.txt): LDS instructions per
+    // sample 3.20 -> 2.57, LDS-array cycles per wave-sample 14.0 -> 11.6, SQ_WAIT_ANY unchanged (0.38), kernel time 11.50 /
+    // 11.65 -> 11.64 / 11.74 ms: the kernel is bound by vector-ALU issue, the LDS pipe has slack, and the DPP form moves
+    // ~0.2 instructions per sample FROM the pipe with slack ONTO the one that binds.
 #ifndef MCX_FLUSH_DPP
-#define MCX_FLUSH_DPP 1
+#define MCX_FLUSH_DPP 0
 #endif
 #if MCX_FLUSH_DPP
     const u32 flush_rel = lane - 48u;             // 0..15 in the lanes that hold the totals, >= 2^32 - 48 elsewhere
@@ -1163,6 +1166,44 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
 #ifndef MCX_MH_PHASED
 #define MCX_MH_PHASED (MCX_BLOCK <= 256)
 #endif
+    // MCX_MH_AHEAD = 4 or 8 (phased loops only; 2 = the plain trip): that many proposals (Box-Muller pairs, table reads,
+    // accept hashes and their logs) ahead of as many accept tests. The small shards that select the phased form run
+    // 2-4 waves per SIMD, where one wave's dependent chain hash -> log/sqrt/sin/cos -> table read -> log -> compare is
+    // exposed: more independent work per trip fills it. The accept tests themselves are unchanged (same expression,
+    // same order): the chains are the same chains, bit for bit. (At full size, 8 waves per SIMD, four ahead measured
+    // slower: 8.79 against 8.54 ms.) Measured on C4's shards: profiles/r03_mh_ahead.txt.
+#ifndef MCX_MH_AHEAD
+#define MCX_MH_AHEAD (MCX_MH_PHASED ? 4 : 2)
+#endif
+#if MCX_MH_AHEAD > 2
+    auto trip_n = [&](auto phase) {               // steps it .. it + MCX_MH_AHEAD - 1
+        constexpr int NP = MCX_MH_AHEAD / 2;
+        float z[2 * NP], xs[2 * NP], ws[2 * NP];
+        u32 ha[2 * NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            mcx_box_muller(mcx_pcg_out(st_prop + (4u * q) * MCX_STATE_STEP), mcx_pcg_angle(st_prop + (4u * q + 1u) * MCX_STATE_STEP),
+                           z[2 * q], z[2 * q + 1]);
+            ha[2 * q] = mcx_pcg_out(st_acc + (2u * q) * MCX_STATE_STEP);
+            ha[2 * q + 1] = mcx_pcg_out(st_acc + (2u * q + 1u) * MCX_STATE_STEP);
+        }
+        st_prop += (4u * NP) * MCX_STATE_STEP;
+        st_acc += (2u * NP) * MCX_STATE_STEP;
+#pragma unroll
+        for (int q = 0; q < 2 * NP; ++q) {
+            xs[q] = MCX_AFFINE(z[q]);
+            const float lp = MCX_LOGP(lp_tb, xs[q]);
+#if MCX_Q_SAMPLER
+            ws[q] = fmaf(0.5f * z[q], z[q], lp);
+#else
+            ws[q] = lp - MCX_LOGQ(lq_tb, xs[q]);
+#endif
+        }
+#pragma unroll
+        for (int q = 0; q < 2 * NP; ++q) mh_finish(phase, it + (u32)q, xs[q], ws[q], 0.0f, ws[q] - cur_lp, ha[q]);
+        it += 2u * NP;
+    };
+#endif
 #if !MCX_MH_PHASED
     // (Four proposals ahead of four accept tests instead of two: 8.79 against 8.54 ms. Not kept.)
     while (it + 1u <= total_steps) trip(McxPhase<0>{});
@@ -1171,6 +1212,9 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
         u32 blk_end = it + (1u << 20);            // the 32-bit accept count of a block cannot overflow
         blk_end = blk_end < a.n_burnin ? blk_end : a.n_burnin;
         blk_end = blk_end < total_steps ? blk_end : total_steps;
+#if MCX_MH_AHEAD > 2
+        while (it + (MCX_MH_AHEAD - 1u) <= blk_end) trip_n(McxPhase<1>{});
+#endif
         while (it + 1u <= blk_end) trip(McxPhase<1>{});
         n_accept += (u64)n_accept_blk;
         n_accept_blk = 0u;
@@ -1179,6 +1223,9 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     while (it + 1u <= total_steps) {
         u32 blk_end = it + 2u * MCX_FLUSH - 1u - since_flush;         // last step of this block
         blk_end = blk_end < total_steps ? blk_end : total_steps;
+#if MCX_MH_AHEAD > 2
+        while (it + (MCX_MH_AHEAD - 1u) <= blk_end) trip_n(McxPhase<2>{});
+#endif
         while (it + 1u <= blk_end) trip(McxPhase<2>{});
         n_accept += (u64)n_accept_blk;
         n_accept_blk = 0u;
