@@ -77,6 +77,7 @@ for cfg in ("c2", "c3", "c4", "c5"):
             span_ns = sum(spans) / len(spans)
     counters = collections.OrderedDict()
     meta = {}
+    gui_ns = {}
     for p in ("a", "b", "fetch", "write"):
         f = latest(f"{cfg}_pmc_{p}/*/*_counter_collection.csv")
         if f is None:
@@ -85,6 +86,8 @@ for cfg in ("c2", "c3", "c4", "c5"):
         for r in csv.DictReader(open(f)):
             if r["Kernel_Name"].startswith(MAIN):
                 per_dispatch[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+                if r["Counter_Name"] == "GRBM_GUI_ACTIVE":           # this pass's own duration of the dispatch (the counter passes
+                    gui_ns[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])      # serialise kernels)
                 meta = {k: r.get(k, "") for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count")}
         names = sorted({c for d in per_dispatch.values() for c in d})
         for c in names:
@@ -131,9 +134,10 @@ for cfg in ("c2", "c3", "c4", "c5"):
         # LDS-array cycles summed over CUs against the shader cycles of the launch (GRBM_GUI_ACTIVE is summed over 8 XCDs)
         # (two launches of a segmented call share the chip: the busy fraction is per launch-time, summed over what overlaps)
         d["lds_array_busy_frac"] = get("SQ_LDS_IDX_ACTIVE") / (get("GRBM_GUI_ACTIVE") / 8.0 * 256.0)
-    if get("GRBM_GUI_ACTIVE") and avg_ns:
-        # busy cycles of one launch over its duration (per-call counter / launches per call)
-        d["effective_clock_ghz"] = get("GRBM_GUI_ACTIVE") / launches / 8.0 / avg_ns
+    if get("GRBM_GUI_ACTIVE") and gui_ns:
+        # busy cycles of one launch (per-call counter / launches per call; summed over 8 XCDs) over the duration the SAME
+        # dispatch had in that counter pass
+        d["effective_clock_ghz"] = get("GRBM_GUI_ACTIVE") / launches / 8.0 / (sum(gui_ns.values()) / len(gui_ns))
     # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide
     # coalesced reads (MI355X_MICROARCH.md, HBM), so the read side is doubled for the upper estimate
     if get("FETCH_SIZE") is not None:
