@@ -47,7 +47,7 @@ def main():
     calls = 0
     first = None
     while time.time() - t0 < args.seconds:
-        kind = int(rng.integers(0, 11))
+        kind = int(rng.integers(0, 13))
         mc = MonteCarloIntegrator(target_threads=int(rng.choice([256, 4096, 65536])), rng=str(rng.choice(["pcg_ref", "philox"])),
                                   std_error=bool(rng.integers(0, 2)))
         fns = make_fn(float(rng.integers(1, 40)) / 8.0)[: int(rng.integers(1, 5))]
@@ -83,8 +83,6 @@ def main():
             assert np.allclose(r.values, g.values, rtol=5e-6, atol=5e-6), (r.values, g.values)
         elif kind == 7:
             # one process, three engines on this GPU (host-sum path of MonteCarloIntegrator(devices=[...])), split launches
-            from wgpu_montecarlo import runtime as rt
-
             multi = MonteCarloIntegrator(devices=[0, 0, 0], rng=str(rng.choice(["pcg_ref", "philox"])))
             rt.set_max_launch_units(int(rng.choice([0, 1_000_000, 7_000_000])))
             try:
@@ -109,6 +107,36 @@ def main():
                 plain._engine.set_mcmc_segments(rt.SEGMENTS_AUTO)
             assert r.meta["accept_rate"] == one.meta["accept_rate"], (kw, r.meta["accept_rate"], one.meta["accept_rate"])
             assert np.allclose(r.values, one.values, rtol=5e-6, atol=5e-6), (kw, r.values, one.values)
+        elif kind == 11:
+            # the plan cache: a repeat call (new lambda objects, same code and captures) must give the first call's result bit
+            # for bit; a changed capture must not be answered from the cache; a full-size default-segmented MCMC call
+            # against its one-launch form
+            scale = float(rng.integers(1, 40)) / 8.0
+            family = lambda c: [lambda x: x * c, lambda x: x * x + c]         # closure captures, one code object per slot
+            dist = Distribution.normal(0.25, 1.5)
+            a = mc.integrate(family(scale), dist, n_samples=n, seed=calls)
+            b = mc.integrate(family(scale), dist, n_samples=n, seed=calls)
+            r = mc.integrate(family(scale + 1.0), dist, n_samples=n, seed=calls)
+            assert np.array_equal(a.values, b.values), (a.values, b.values)
+            assert abs(r.values[0] * scale - a.values[0] * (scale + 1.0)) < 1e-5 * (1.0 + abs(a.values[0])) * (scale + 1.0), (a.values, r.values)
+            assert abs((r.values[1] - a.values[1]) - 1.0) < 1e-5 * (1.0 + abs(a.values[1])), (a.values, r.values)
+        elif kind == 12:
+            # blocking calls of every size class through the pinned-result / ticket-polling path against the copy + stream-wait path
+            big = int(rng.choice([1000, 3_000_000, 400_000_000]))
+            r = mc.integrate(fns, Distribution.normal(0.1, 1.1), n_samples=big, seed=calls)
+            os.environ["MCX_POLL_US"] = "0"
+            os.environ["MCX_NO_ZERO_COPY"] = "1"
+            try:
+                plain = rt.Engine(0)                        # a fresh engine reads the two knobs
+                other = MonteCarloIntegrator(target_threads=mc._target_threads, rng="pcg_ref" if mc._rng == 0 else "philox",
+                                             std_error=mc._std_error)
+                other._engine = plain
+                other._engines = [plain]
+                g = other.integrate(fns, Distribution.normal(0.1, 1.1), n_samples=big, seed=calls)
+                plain.close()
+            finally:
+                del os.environ["MCX_POLL_US"], os.environ["MCX_NO_ZERO_COPY"]
+            assert np.array_equal(r.values, g.values), (r.values, g.values)
         elif kind == 10:
             # importance sampling / MH with padded, unclamped cell tables against the clamped lookup
             xs = np.linspace(-3.0, 4.0, int(rng.choice([200, 512, 1500])))

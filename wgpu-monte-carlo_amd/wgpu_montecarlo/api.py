@@ -437,14 +437,19 @@ class MonteCarloIntegrator:
         return total
 
     def _replicas(self, plan: "_Plan"):
-        """[(engine, module, tables)] of a plan on every device of this integrator (built on first use)."""
+        """[(engine, module, tables)] of a plan on every device of this integrator (built on first use). Plans are cached per
+        engine and shared by integrators, which may drive different device sets: the replicas are kept per engine set."""
+        key = tuple(id(e) for e in self._engines)
         if plan.replicas is None:
+            plan.replicas = {}
+        reps = plan.replicas.get(key)
+        if reps is None:
             reps = [(self._engine, plan.module, plan.tables)]
             for eng in self._engines[1:]:
                 tabs = {k: (eng.cached_table(t.kind, t.keys, t.values) if t is not None else None) for k, t in plan.tables.items()}
                 reps.append((eng, eng.module(plan.module.user_src, plan.desc), tabs))
-            plan.replicas = reps
-        return plan.replicas
+            plan.replicas[key] = reps
+        return reps
 
     def _run_devices(self, plan: "_Plan", sizes, seed: int):
         """One host thread, several devices: device r runs shard r of len(devices); libmcx joins them."""
