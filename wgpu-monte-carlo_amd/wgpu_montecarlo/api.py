@@ -442,13 +442,18 @@ class MonteCarloIntegrator:
         key = tuple(id(e) for e in self._engines)
         if plan.replicas is None:
             plan.replicas = {}
-        reps = plan.replicas.get(key)
-        if reps is None:
-            reps = [(self._engine, plan.module, plan.tables)]
-            for eng in self._engines[1:]:
-                tabs = {k: (eng.cached_table(t.kind, t.keys, t.values) if t is not None else None) for k, t in plan.tables.items()}
-                reps.append((eng, eng.module(plan.module.user_src, plan.desc), tabs))
-            plan.replicas[key] = reps
+        hit = plan.replicas.get(key)
+        # the entry keeps the engine objects alive, so an id() cannot be re-used by another engine; an engine that was
+        # closed since (its modules and tables are gone) invalidates the entry
+        if hit is not None and all(a is b and b._h for a, b in zip(hit[0], self._engines)):
+            return hit[1]
+        reps = [(self._engine, plan.module, plan.tables)]
+        for eng in self._engines[1:]:
+            tabs = {k: (eng.cached_table(t.kind, t.keys, t.values) if t is not None else None) for k, t in plan.tables.items()}
+            reps.append((eng, eng.module(plan.module.user_src, plan.desc), tabs))
+        for stale in [k for k, (engines, _) in plan.replicas.items() if not all(e._h for e in engines)]:
+            del plan.replicas[stale]
+        plan.replicas[key] = (list(self._engines), reps)
         return reps
 
     def _run_devices(self, plan: "_Plan", sizes, seed: int):
