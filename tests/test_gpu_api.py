@@ -280,3 +280,25 @@ def test_concurrent_host_threads_share_one_engine(mc):
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_auto_stream_uses_the_parity_stream_within_its_counter_space_and_philox_beyond():
+    """MonteCarloIntegrator(rng="auto"): a call of <= 2^32 draws is the reference stream's call bit for bit; a larger one
+    (here 6e9 samples of K = 2) runs on Philox, says so in meta["rng"], does not warn, and lands within 3 sigma."""
+    import warnings
+
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+
+    fns = [lambda x: x, lambda x: x * x]
+    dist = Distribution.normal(0.0, 1.0)
+    auto, ref = MonteCarloIntegrator(rng="auto"), MonteCarloIntegrator(rng="pcg_ref")
+    a, b = auto.integrate(fns, dist, n_samples=10**7, seed=3), ref.integrate(fns, dist, n_samples=10**7, seed=3)
+    assert a.meta["rng"] == b.meta["rng"] == "pcg_ref" and np.array_equal(a.values, b.values)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                       # the oversubscription warning must not fire for the auto policy
+        big = auto.integrate(fns, dist, n_samples=6 * 10**9, seed=3)
+    assert big.meta["rng"] == "philox"
+    sigma = np.sqrt(np.array([1.0, 2.0]) / big.meta["n_eff"])
+    assert np.all(np.abs(big.values - [0.0, 1.0]) < 3.5 * sigma), big.values
+    mh = auto.integrate_mcmc(fns, Distribution.normal(0.5, 1.0), Distribution.normal(0.0, 2.0), n_steps=50, n_chains=4096, n_burnin=10)
+    assert mh.meta["rng"] == "pcg_ref"

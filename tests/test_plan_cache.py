@@ -129,3 +129,22 @@ def test_lds_decisions_are_rechecked_against_the_code_objects_real_static_lds(mo
     monkeypatch.setattr(rt.HostModule, "__init__", inflated(158 * 1024))      # beyond the CU: tables from HBM / L2
     plan = mc._plan_mcmc(fns, target, proposal, block=0)
     assert (plan.desc.tables_lds, plan.desc.cell_noclamp, plan.desc.cell_addr16) == (0, 0, 0)
+
+
+def test_auto_stream_policy_picks_philox_only_beyond_the_reference_streams_counter_space():
+    """rng="auto": the reference's hash for every call that stays within its 2^32 inputs (parity stream), Philox for the
+    calls that draw more. The choice is per call, and the two streams' plans are separate cache entries."""
+    from wgpu_montecarlo import runtime as rt
+
+    auto = MonteCarloIntegrator.planner(rng="auto")
+    assert auto._pick_rng(10**9) == rt.RNG_PCG_REF and auto._pick_rng(2**32) == rt.RNG_PCG_REF
+    assert auto._pick_rng(2**32 + 1) == rt.RNG_PHILOX and auto._pick_rng(10**10) == rt.RNG_PHILOX
+    assert MonteCarloIntegrator.planner(rng="pcg_ref")._pick_rng(10**12) == rt.RNG_PCG_REF
+    assert MonteCarloIntegrator.planner(rng="philox")._pick_rng(10) == rt.RNG_PHILOX
+    dist = Distribution.normal(0.0, 1.0)
+    fns = [lambda x: x * x]
+    small = auto._cached_plan("integrate", fns, (dist,), None, lambda: auto._plan_integrate(fns, dist, rt.RNG_PCG_REF), rt.RNG_PCG_REF)
+    large = auto._cached_plan("integrate", fns, (dist,), None, lambda: auto._plan_integrate(fns, dist, rt.RNG_PHILOX), rt.RNG_PHILOX)
+    assert small.desc.rng == rt.RNG_PCG_REF and large.desc.rng == rt.RNG_PHILOX and small is not large
+    with pytest.raises(ValueError, match="'pcg_ref'.*'philox' or 'auto'"):
+        MonteCarloIntegrator.planner(rng="xoshiro")

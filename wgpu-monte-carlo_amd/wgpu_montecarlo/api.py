@@ -272,7 +272,11 @@ class MonteCarloIntegrator:
             (reference behaviour, can produce log(0)); default False guards the end points.
         rng: "pcg_ref" (default) is the reference's counter hash -- bit-exact sample indexing, but a 32-bit
             counter space that is oversubscribed beyond ~4e9 uniforms per call; "philox" is Philox4x32-10 with a
-            128-bit counter (four iterations per call for integrate / importance sampling, one call per two MH steps).
+            128-bit counter (four iterations per call for integrate / importance sampling, one call per two MH steps);
+            "auto" uses the reference's stream for every call that stays within its 2^32 counter space -- where it is
+            the parity stream and its estimates converge -- and Philox for the calls that draw more (BASELINE's
+            1 048 576-chain MCMC: 2.3e10 uniforms; 1e10-sample integrals), where the reference's own estimates sit
+            ~2 sigma off on average (profiles/r03_seed_sweep_c2_c5.jsonl). meta["rng"] says which one a call used.
         devices: several HIP device indices driven by THIS process (no torch.distributed): every call is sharded over
             them from one host thread and joined by libmcx's own RCCL communicator (include/mcx.h: mcx_comm_create --
             one grouped ncclAllReduce of the K doubles over xGMI), or by a host-side sum when a device is listed more
@@ -298,9 +302,10 @@ class MonteCarloIntegrator:
         runtime.load()                               # ImportError if libmcx.so has not been built
         if math not in ("default", "fast", "precise"):
             raise ValueError("math must be 'default', 'fast' or 'precise'")
-        if rng not in runtime.RNG_CODES:
-            raise ValueError("rng must be 'pcg_ref' (the reference's stream) or 'philox'")
-        self._rng = runtime.RNG_CODES[rng]
+        if rng not in runtime.RNG_CODES and rng != "auto":
+            raise ValueError("rng must be 'pcg_ref' (the reference's stream), 'philox' or 'auto'")
+        self._rng_auto = rng == "auto"
+        self._rng = runtime.RNG_PCG_REF if self._rng_auto else runtime.RNG_CODES[rng]
         self._std_error = bool(std_error)
         if devices is not None:
             devices = [int(d) for d in devices]
@@ -336,8 +341,13 @@ class MonteCarloIntegrator:
         # what a plan depends on besides the functions and distributions (plans are cached per engine, shared by integrators)
         self._mode = (math, self._guard, self._rng, self._std_error)
 
+    def _pick_rng(self, draws: int) -> int:
+        """The stream a call that draws `draws` uniforms uses: the integrator's own, or with rng="auto" Philox beyond the
+        2^32 counter space of the reference's hash."""
+        return runtime.RNG_PHILOX if (self._rng_auto and draws > (1 << 32)) else self._rng
+
     # ---- plan cache -------------------------------------------------------------------------------
-    def _cached_plan(self, kind: str, functions, dists, extra, build):
+    def _cached_plan(self, kind: str, functions, dists, extra, build, rng: Optional[int] = None):
         """The compiled plan of a repeat call: one dict lookup on (function fingerprints, distribution identities, mode)
         instead of lowering, emission, desc fitting and module lookup (the reference re-transpiles and re-compiles per
         call, src/engine.rs:325-331). Anything unhashable or outside the emitter's subset takes the uncached path, which
@@ -347,7 +357,7 @@ class MonteCarloIntegrator:
             return build()
         try:
             key = (kind, tuple([_function_key(f) for f in functions]), tuple([_distribution_key(d) for d in dists]),
-                   self._mode, extra, _env_key())
+                   self._mode, self._rng if rng is None else rng, extra, _env_key())
             hit = cache.get(key)
         except (TypeError, TranspilerError, AttributeError):
             return build()
@@ -497,11 +507,11 @@ class MonteCarloIntegrator:
             sums = distributed.all_reduce_host(g, sums)
         return sums / float(n_eff), n_eff
 
-    def _warn_if_oversubscribed(self, n_eff: int, what: str = "n_samples") -> None:
+    def _warn_if_oversubscribed(self, n_eff: int, what: str = "n_samples", rng: Optional[int] = None) -> None:
         """The reference's counter hash has 2^32 distinct inputs. Beyond that many samples per call the estimator
         stops converging: the stream is a finite population whose own mean is off by ~3e-5 (measured: E[x] on N(0,1)
         is 10 sigma low at n = 1e11 and 33 sigma low at 1e12, tools/stream_quality.py / DESIGN.md 4.4)."""
-        if self._rng == runtime.RNG_PCG_REF and n_eff > (1 << 32) and not getattr(self, "_warned_stream", False):
+        if (self._rng if rng is None else rng) == runtime.RNG_PCG_REF and n_eff > (1 << 32) and not getattr(self, "_warned_stream", False):
             import warnings
 
             self._warned_stream = True
@@ -535,7 +545,8 @@ class MonteCarloIntegrator:
         return (self._group.rank, self._group.world) if self._group is not None else (0, 1)
 
     # ---- plans: emission + compilation + resident tables, no launch -----------------------------------
-    def _plan_integrate(self, functions, distribution) -> _Plan:
+    def _plan_integrate(self, functions, distribution, rng: Optional[int] = None) -> _Plan:
+        rng = self._rng if rng is None else rng
         if len(functions) == 0:
             raise ValueError("At least one function is required")
         user_src = functions_to_hip(functions, self._math)
@@ -543,14 +554,15 @@ class MonteCarloIntegrator:
         cdf = self._cdf_table(distribution)
         k = len(functions)
         desc = runtime.make_desc(runtime.KIND_INTEGRATE, k, code, guard_endpoints=self._guard,
-                                 precise_sampler=self._precise_sampler, rng=self._rng,
+                                 precise_sampler=self._precise_sampler, rng=rng,
                                  second_moments=self._std_error, unit_params=_unit_params(code, p1, p2),
                                  moment_family=self._use_moment_family(functions), cdf_direct=self._cdf_direct(cdf, k))
         self._fit_tables(desc, cdf)
         return _Plan("integrate", self._build_module(user_src, desc, cdf), desc, k, runtime.result_rows(desc), p1, p2,
                      dict(cdf=cdf))
 
-    def _plan_importance_sampling(self, functions, target_distribution, proposal_distribution) -> _Plan:
+    def _plan_importance_sampling(self, functions, target_distribution, proposal_distribution, rng: Optional[int] = None) -> _Plan:
+        rng = self._rng if rng is None else rng
         if len(functions) == 0:
             raise ValueError("At least one function is required")
         p_src = _pdf_to_hip(target_distribution, "mcx_pdf_p", self._math)
@@ -579,7 +591,7 @@ class MonteCarloIntegrator:
         desc = runtime.make_desc(runtime.KIND_INTEGRATE, k, code, weight=True,
                                  p_table=p_table is not None, q_table=q_table is not None,
                                  guard_endpoints=self._guard, precise_sampler=self._precise_sampler,
-                                 rng=self._rng, second_moments=self._std_error,
+                                 rng=rng, second_moments=self._std_error,
                                  unit_params=_unit_params(code, p1, p2),
                                  cell_tables=cells, q_sampler=q_sampler, cell_noclamp=pad_bytes is not None,
                                  moment_family=self._use_moment_family(functions), cdf_direct=self._cdf_direct(cdf, k))
@@ -598,7 +610,8 @@ class MonteCarloIntegrator:
         return 0 if hint >= 1024 else hint
 
     def _plan_mcmc(self, functions, target_distribution, proposal_distribution, proposal_kind="independent",
-                   initial_state=0.0, target_accept=0.44, block: int = 0) -> _Plan:
+                   initial_state=0.0, target_accept=0.44, block: int = 0, rng: Optional[int] = None) -> _Plan:
+        rng = self._rng if rng is None else rng
         if proposal_kind not in ("independent", "random_walk", "adaptive_random_walk"):
             raise ValueError(f"Unknown proposal_kind: {proposal_kind!r} (expected 'independent', 'random_walk' or "
                              f"'adaptive_random_walk')")
@@ -632,7 +645,7 @@ class MonteCarloIntegrator:
         # independent proposals: every lookup is at a draw of the proposal, whose range is known -> no index clamp
         pad_bytes = self._cell_pads(cells, code, p1, p2, cdf, t_table, q_table) if walk == runtime.WALK_INDEPENDENT else None
         desc = runtime.make_desc(runtime.KIND_MCMC, k, code, guard_endpoints=self._guard,
-                                 precise_sampler=self._precise_sampler, rng=self._rng, block=block,
+                                 precise_sampler=self._precise_sampler, rng=rng, block=block,
                                  unit_params=_unit_params(code, p1, p2), second_moments=self._std_error, walk=walk,
                                  cell_tables=cells, q_sampler=q_sampler, cell_noclamp=pad_bytes is not None)
         self._fit_tables(desc, cdf, t_table, q_table, extra_bytes=pad_bytes or 0)
@@ -659,27 +672,29 @@ class MonteCarloIntegrator:
     def integrate(self, functions: List[FunctionLike], distribution: Distribution, n_samples: int = 1_000_000,
                   seed: int = 42) -> IntegrationResult:
         """E[f_k(X)], X ~ distribution, for all functions on the same samples."""
-        plan = self._cached_plan("integrate", functions, (distribution,), None,
-                                 lambda: self._plan_integrate(functions, distribution))
         n_samples = _check_count(n_samples, "n_samples")
         seed = _check_seed(seed)
+        rng = self._pick_rng(n_samples)
+        plan = self._cached_plan("integrate", functions, (distribution,), None,
+                                 lambda: self._plan_integrate(functions, distribution, rng), rng)
         values, n_eff = self._run(plan.rows, lambda d_sums, stream: self._enqueue(plan, n_samples, seed, d_sums, stream),
                                   plan, n_samples, seed)
-        self._warn_if_oversubscribed(n_eff)
-        return IntegrationResult(values[:plan.k], n_samples, plan.k, self._meta(n_eff, values, plan.k))
+        self._warn_if_oversubscribed(n_eff, rng=rng)
+        return IntegrationResult(values[:plan.k], n_samples, plan.k, self._meta(n_eff, values, plan.k, rng))
 
     # ---- K2 ----------------------------------------------------------------------------------------
     def integrate_importance_sampling(self, functions: List[FunctionLike], target_distribution: Distribution,
                                       proposal_distribution: Distribution, n_samples: int = 1_000_000,
                                       seed: int = 42) -> IntegrationResult:
         """E_p[f_k(X)] ~= mean f_k(x) p(x)/q(x), x ~ q."""
-        plan = self._cached_plan("is", functions, (target_distribution, proposal_distribution), None,
-                                 lambda: self._plan_importance_sampling(functions, target_distribution, proposal_distribution))
         n_samples = _check_count(n_samples, "n_samples")
         seed = _check_seed(seed)
+        rng = self._pick_rng(n_samples)
+        plan = self._cached_plan("is", functions, (target_distribution, proposal_distribution), None,
+                                 lambda: self._plan_importance_sampling(functions, target_distribution, proposal_distribution, rng), rng)
         values, n_eff = self._run(plan.rows, lambda d_sums, stream: self._enqueue(plan, n_samples, seed, d_sums, stream),
                                   plan, n_samples, seed)
-        return IntegrationResult(values[:plan.k], n_samples, plan.k, self._meta(n_eff, values, plan.k))
+        return IntegrationResult(values[:plan.k], n_samples, plan.k, self._meta(n_eff, values, plan.k, rng))
 
     # ---- K3 ----------------------------------------------------------------------------------------
     def integrate_mcmc(self, functions: List[FunctionLike], target_distribution: Distribution,
@@ -707,13 +722,15 @@ class MonteCarloIntegrator:
         n_steps, n_chains, n_burnin = self._check_mcmc_sizes(n_steps, n_chains, n_burnin)
         seed = _check_seed(seed)
         block = self._mcmc_block(n_chains)
+        padded = runtime.mcmc_dispatch_config(n_chains, self._target_threads).total_threads
+        rng = self._pick_rng(2 * padded * (n_steps + n_burnin))          # one proposal + one accept uniform per step
         plan = self._cached_plan("mcmc", functions, (target_distribution, proposal_distribution),
                                  (proposal_kind, float(initial_state), float(target_accept), block),
                                  lambda: self._plan_mcmc(functions, target_distribution, proposal_distribution, proposal_kind,
-                                                         initial_state, target_accept, block=block))
+                                                         initial_state, target_accept, block=block, rng=rng), rng)
         values, n_eff = self._run(plan.rows, lambda d_sums, stream: self._enqueue(
             plan, (n_steps, n_chains, n_burnin), seed, d_sums, stream), plan, (n_steps, n_chains, n_burnin), seed)
-        return self._mcmc_result(plan, values, n_eff, n_steps, n_chains, n_burnin)
+        return self._mcmc_result(plan, values, n_eff, n_steps, n_chains, n_burnin, rng)
 
     @staticmethod
     def _check_mcmc_sizes(n_steps, n_chains, n_burnin):
@@ -726,15 +743,16 @@ class MonteCarloIntegrator:
         return (_check_count(n_steps, "n_steps", 32), _check_count(n_chains, "n_chains", 32),
                 _check_count(n_burnin, "n_burnin", 32))
 
-    def _mcmc_result(self, plan: _Plan, values, n_eff: int, n_steps: int, n_chains: int, n_burnin: int) -> IntegrationResult:
+    def _mcmc_result(self, plan: _Plan, values, n_eff: int, n_steps: int, n_chains: int, n_burnin: int,
+                     rng: Optional[int] = None) -> IntegrationResult:
         """values = all-rank sums / n_eff for every result row of an MCMC plan -> the public result + diagnostics."""
         k = plan.k
-        meta = self._meta(n_eff)
+        meta = self._meta(n_eff, rng=rng)
         total_chains = n_eff // n_steps
         # chains whose counters collide replay each other's random numbers with a time shift: the estimate stays
         # consistent but the chains are no longer independent (measured at C4's size with random-walk proposals:
         # 5-7 batch-means standard errors off with the reference stream, 0.4 with Philox; DESIGN.md 4.5)
-        self._warn_if_oversubscribed(2 * total_chains * (n_steps + n_burnin), "uniform draws (chains x steps x 2)")
+        self._warn_if_oversubscribed(2 * total_chains * (n_steps + n_burnin), "uniform draws (chains x steps x 2)", rng=rng)
         row_accept = 2 * k if self._std_error else k
         meta["accept_rate"] = float(values[row_accept]) * n_eff / (float(total_chains) * (n_steps + n_burnin))
         meta["proposal_kind"] = plan.proposal_kind
@@ -773,10 +791,11 @@ class MonteCarloIntegrator:
                                              initial_state, target_accept, block=block)
         return PreparedMcmc(self, make(0), make)
 
-    def _meta(self, n_eff: int, values=None, k: int = 0) -> dict:
+    def _meta(self, n_eff: int, values=None, k: int = 0, rng: Optional[int] = None) -> dict:
         meta = self._engine.last_call()               # n_blocks, block, lds_bytes, launches, kernel_ms: one C call
         rank, world = self._rank_world()
         meta["n_eff"], meta["rank"], meta["world"] = n_eff, rank, world
+        meta["rng"] = "philox" if (self._rng if rng is None else rng) == runtime.RNG_PHILOX else "pcg_ref"
         meta["devices"] = [e.device for e in self._engines]
         meta["collective"] = ("rccl" if self._comm is not None else "host-sum") if len(self._engines) > 1 else None
         if values is not None and len(values) == 2 * k and k:
