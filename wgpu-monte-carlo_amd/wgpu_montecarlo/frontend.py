@@ -600,8 +600,9 @@ def fingerprint(func: Callable, bind_defaults: bool = True) -> tuple:
     cells = func.__closure__
     g = func.__globals__
     try:
+        kw = func.__kwdefaults__
         return (code, tuple(c.cell_contents for c in cells) if cells else None, func.__defaults__,
-                tuple(g.get(n) for n in names) if names else None)
+                tuple(g.get(n) for n in names) if names else None, tuple(sorted(kw.items())) if kw else None)
     except ValueError:                                          # an empty closure cell
         raise TypeError("closure cell is empty")
 
