@@ -136,7 +136,7 @@ int  mcx_engine_last_call(mcx_engine* e, mcx_call_info* out, int with_timing);
 uint32_t mcx_engine_last_launch_count(const mcx_engine* e);
 /* Tuning knob: physical threads a launch aims for; 0 = the default, 4096 workgroups of the module's size (16 per CU). */
 int  mcx_engine_set_target_threads(mcx_engine* e, uint32_t physical_threads);
-/* Time segments of an MCMC call of the batched independence sampler (normal proposal, reference stream, no
+/* Time segments of an MCMC call of the independence sampler with a normal proposal (either stream; no
  * precise_sampler / second_moments / walk): the call runs as two halves of the chains on two streams, each cut into
  * `segments` launches over consecutive step ranges. A launch that fills the chip a small whole number of times --
  * 1 048 576 chains = exactly twice -- leaves CUs idle while its last workgroups finish; the other half's next segment

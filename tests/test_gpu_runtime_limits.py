@@ -255,7 +255,7 @@ def test_mcmc_time_segments_run_the_same_chains(integrator, segments):
         with torch.cuda.stream(side):
             n_eff = prep.launch(2000, 4096, 300, 11, out)
         side.synchronize()
-        # precise math / Philox / random walk are not the batched sampler: one launch, whatever the setting
+        # precise math / random walks are not segmentable: one launch, whatever the setting
         other = integrator.integrate_mcmc(f2, target, proposal, n_steps=200, n_chains=1024, n_burnin=20, seed=3,
                                           proposal_kind="random_walk")
         assert eng.last_launch()["launches"] == 1 and np.all(np.isfinite(other.values))
@@ -336,3 +336,31 @@ def test_segmented_mcmc_calls_in_flight_on_two_streams_keep_their_own_state(inte
         assert np.array_equal(g[rep, :, 2], w[:, 2]), (rep, g[rep, :, 2], w[:, 2])       # accepted steps: the same chains
         assert np.allclose(g[rep, :, :2] / n_eff, w[:, :2] / n_eff, rtol=2e-6, atol=2e-6)
     assert not np.array_equal(w[0], w[1])
+
+
+@pytest.mark.parametrize("segments", [2, 7])
+def test_philox_mcmc_time_segments_run_the_same_chains(segments):
+    """The Philox stream's MH loop resumes a chain from {x, w} at an even step as well (call index = step / 2): the same
+    chains cut into segments -- identical accepted-step counts -- for odd / even burn-in and a trailing single step."""
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+    from wgpu_montecarlo import runtime as rt
+
+    target = Distribution.from_pdf(lambda x: 0.5 * (np.exp(-0.5 * (x - 2) ** 2) + np.exp(-0.5 * (x + 2) ** 2)), support=(-10, 10))
+    proposal = Distribution.normal(0.0, 2.0)
+    f2 = [lambda x: x, lambda x: x * x]
+    mc = MonteCarloIntegrator(rng="philox")
+    eng = mc._engine
+    cases = [(2000, 4096, 300), (1999, 4096 + 256, 301), (64, 768, 7), (37, 512, 100)]
+    eng.set_mcmc_segments(0)
+    try:
+        plain = [mc.integrate_mcmc(f2, target, proposal, n_steps=s, n_chains=c, n_burnin=b, seed=11) for s, c, b in cases]
+        assert eng.last_launch()["launches"] == 1
+        eng.set_mcmc_segments(segments)
+        cut = [mc.integrate_mcmc(f2, target, proposal, n_steps=s, n_chains=c, n_burnin=b, seed=11) for s, c, b in cases]
+        assert eng.last_launch()["segments"] == segments
+    finally:
+        eng.set_mcmc_segments(rt.SEGMENTS_AUTO)
+    for a, b, case in zip(plain, cut, cases):
+        assert a.meta["rng"] == b.meta["rng"] == "philox"
+        assert a.meta["accept_rate"] == b.meta["accept_rate"], case
+        assert np.allclose(a.values, b.values, rtol=2e-6, atol=2e-6), (case, a.values, b.values)

@@ -1112,8 +1112,22 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
     };
 #endif
 #if MCX_RNG == 1
+    // time segments (host: mcmc_impl) for the Philox stream as well: a later segment resumes (x, w) at an even step; the
+    // call index it >> 1 and the halves of its four outputs follow from `it` alone
+#define MCX_MH_SEG_PHILOX (MCX_W_STATE && MCX_DIST == MCX_DIST_NORMAL)
+    u32 it_first = 2u;
+#if MCX_MH_SEG_PHILOX
+    if (a.it_begin > 1u) {
+        it_first = a.it_begin;
+        if (active) {
+            const float2 st = ((const float2*)a.seg_state)[g];
+            cur_x = st.x;
+            cur_lp = st.y;
+        }
+    } else
+#endif
     if (total_steps >= 1u) mh_step_h(1u, ph_odd_draw, ph_odd_accept);
-    for (u32 it = 2u; it <= total_steps; it += 2u) {
+    for (u32 it = it_first; it <= total_steps; it += 2u) {
         const McxU4 o = mcx_philox4x32_10(McxU4{idx, it >> 1, 1u, 0u}, a.seed, MCX_PHILOX_KEY1);
 #if MCX_DIST == MCX_DIST_NORMAL
         float z0, z1;
@@ -1125,6 +1139,14 @@ mcx_mcmc_kernel(McxMcmcArgs a) {
         if (it + 1u <= total_steps) mh_step_h(it + 1u, mcx_draw_proposal(o.y, pv, cdf_tb), o.w);
 #endif
     }
+#if MCX_MH_SEG_PHILOX
+    if (a.seg_state != nullptr && active) {
+        float2 st;
+        st.x = cur_x;
+        st.y = cur_lp;
+        ((float2*)a.seg_state)[g] = st;
+    }
+#endif
 #elif MCX_DIST == MCX_DIST_NORMAL
     // odd `it` consumes the z1 cached by the previous draw (it = 1: the initial draw's), even `it` draws a
     // new pair from counters 2*(it+OFFSET), +1 (distribution.rs:90-114 through shader_gen.rs:481)
