@@ -13,6 +13,9 @@ For each: kernel time of `bench.py --config c5` (main + fold, HIP events, 2 runs
 rocprofv3 --pmc passes over the same command (instruction counts; LDS bank conflicts / busy cycles / waits).
 Run on the GPU box from the repo root:   python3 tools/ab_c5_lds.py > gpurun_out/r03_c5_lds_variants.txt
 This process never touches the GPU: every measurement is a child process.
+
+The variants lost (profiles/r03_c5_lds_variants.txt) and their code paths (MCX_FLUSH_DPP, MCX_DIRECT_SOA) were removed from
+device/mcx_kernels.hpp afterwards: to re-run this comparison check out commit 9b35320, where they exist.
 """
 import collections
 import csv

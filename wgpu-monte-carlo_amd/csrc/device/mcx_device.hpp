@@ -277,28 +277,10 @@ struct McxCdfDirect {
     const float2* kv;          // global {cdf, x}
     const float* slopes;       // global dx/dcdf per cell
     u32 shift, mask;           // per-lane copies (mcx_in_vgpr_u32): bucket = h >> shift, low bits = h & mask
-    u32 plane;                 // MCX_DIRECT_SOA: records staged as two planes of `plane` floats
 };
-#ifndef MCX_DIRECT_SOA
-#define MCX_DIRECT_SOA 0
-#endif
-// the record of the draw's bucket: one 8-byte LDS read (default), or one 4-byte read from each plane
-MCX_DEV float2 mcx_cdf_rec(const McxCdfDirect& cd, u32 h) {
-#if MCX_DIRECT_SOA
-    const __attribute__((address_space(3))) float* px = (const __attribute__((address_space(3))) float*)cd.rec;
-    const u32 b = h >> cd.shift;
-    float2 r;
-    r.x = px[b];
-#if MCX_DIRECT_SOA == 2
-    r.y = px[8192u + b];            // compile-time plane distance (the 8192-record tables only): one ds_read2st64_b32
-#else
-    r.y = px[cd.plane + b];
-#endif
-    return r;
-#else
-    return cd.rec[h >> cd.shift];
-#endif
-}
+// the record of the draw's bucket: one 8-byte LDS read. (Measured and not kept, round 3: the records as two 4-byte planes --
+// 1.7x the bank-conflict cycles, slower or equal; profiles/r03_c5_lds_variants.txt, code in commit 9b35320.)
+MCX_DEV float2 mcx_cdf_rec(const McxCdfDirect& cd, u32 h) { return cd.rec[h >> cd.shift]; }
 // The flag test as ONE v_cmp whose SGPR-pair result is the wave's ballot: bit l = lane l's record is flagged. The
 // per-lane predicate is recovered with inverse_ballot (the mask itself becomes the exec mask: no second compare, no
 // v_cndmask / v_cmp_ne round trip). volatile: the compare reads EXEC implicitly and must stay where it is written.
@@ -520,26 +502,6 @@ MCX_DEV double mcx_wave_sum(double v) {
 MCX_DEV float mcx_wave_sum_f32(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-// The same sum on the vector ALU alone (DPP; gfx9-family cross-lane modifiers): __shfl_xor is ds_bpermute_b32, which
-// travels through the LDS pipe -- the pipe the table gathers of the K > 8 kernels live on. quad_perm [1,0,3,2] and
-// [2,3,0,1] give every lane its quad's sum, row_half_mirror its half-row's, row_mirror its row's (16 lanes);
-// row_bcast:15 adds row r's total to row r + 1 (rows 1 and 3), row_bcast:31 adds lane 31 -- rows 0 + 1 -- to rows 2 and 3.
-// The wave's total is valid in LANES 48..63 ONLY.
-template <int CTRL, int ROW_MASK>
-MCX_DEV float mcx_dpp_add(float v) {
-    // v_mov_b32_dpp with old = 0: rows outside ROW_MASK and lanes without a source read 0
-    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true);
-    return v + __builtin_bit_cast(float, moved);
-}
-MCX_DEV float mcx_wave_sum_f32_dpp(float v) {
-    v = mcx_dpp_add<0xB1, 0xf>(v);        // quad_perm:[1,0,3,2]
-    v = mcx_dpp_add<0x4E, 0xf>(v);        // quad_perm:[2,3,0,1]
-    v = mcx_dpp_add<0x141, 0xf>(v);       // row_half_mirror
-    v = mcx_dpp_add<0x140, 0xf>(v);       // row_mirror
-    v = mcx_dpp_add<0x142, 0xa>(v);       // row_bcast:15 row_mask:0xa
-    v = mcx_dpp_add<0x143, 0xc>(v);       // row_bcast:31 row_mask:0xc
     return v;
 }
 MCX_DEV u32 mcx_wave_sum_u32(u32 v) {

@@ -188,18 +188,7 @@ MCX_DEV McxCdfDirect mcx_stage_cdf_direct(const McxTableDesc& d, u32& off) {
     cd.slopes = d.slopes;
     __attribute__((address_space(3))) float2* dst = (__attribute__((address_space(3))) float2*)(mcx_lds_raw + off);
     const u32 dn = 1u << d.direct_bits;
-#if MCX_DIRECT_SOA
-    // experiment (profiles/r03_c5_lds_variants.txt): the records as two 4-byte planes {x_b}[G], {slope}[G] instead of 8-byte pairs
-    __attribute__((address_space(3))) float* px = (__attribute__((address_space(3))) float*)dst;
-    for (u32 i = threadIdx.x; i < dn; i += MCX_BLOCK) {
-        const float2 r = ((const float2*)d.direct)[i];
-        px[i] = r.x;
-        px[dn + i] = r.y;
-    }
-    cd.plane = dn;
-#else
     for (u32 i = threadIdx.x; i < dn; i += MCX_BLOCK) dst[i] = ((const float2*)d.direct)[i];
-#endif
     off += dn * 8u;
     cd.rec = dst;
     return cd;
@@ -393,30 +382,9 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
     __shared__ double wave_sums[MCX_WAVES][MCX_K];
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane < (u32)MCX_K) wave_sums[wave][lane] = 0.0;
-    // MCX_FLUSH_DPP=1 (experiment, NOT the default): the K wave totals formed by DPP adds on the vector ALU
-    // (mcx_wave_sum_f32_dpp: valid in lanes 48..63) instead of 6 ds_bpermute_b32 per row on the LDS pipe, lane 48 + k % 16
-    // keeping row k's total and 16 lanes updating the f64 slots in LDS at once -- ceil(K / 16) read-modify-writes per
-    // flush instead of K dependent ones by lane 0. Measured on C5 (profiles/r03_c5_lds_variants.txt): LDS instructions per
-    // sample 3.20 -> 2.57, LDS-array cycles per wave-sample 14.0 -> 11.6, SQ_WAIT_ANY unchanged (0.38), kernel time 11.50 /
-    // 11.65 -> 11.64 / 11.74 ms: the kernel is bound by vector-ALU issue, the LDS pipe has slack, and the DPP form moves
-    // ~0.2 instructions per sample FROM the pipe with slack ONTO the one that binds.
-#ifndef MCX_FLUSH_DPP
-#define MCX_FLUSH_DPP 0
-#endif
-#if MCX_FLUSH_DPP
-    const u32 flush_rel = lane - 48u;             // 0..15 in the lanes that hold the totals, >= 2^32 - 48 elsewhere
-#define MCX_FLUSH_ACC()                                                                     \
-    do {                                                                                    \
-        float mine_[(MCX_K + 15) / 16];                                                     \
-        _Pragma("unroll") for (int g = 0; g < (MCX_K + 15) / 16; ++g) mine_[g] = 0.0f;     \
-        _Pragma("unroll") for (int k = 0; k < MCX_K; ++k) {                                 \
-            const float s_ = mcx_wave_sum_f32_dpp(MCX_PAIR_LANES ? MCX_ACC_A(k) + MCX_ACC_B(k) : MCX_ACC_A(k)); \
-            mine_[k / 16] = flush_rel == (u32)(k % 16) ? s_ : mine_[k / 16];                \
-        }                                                                                   \
-        _Pragma("unroll") for (int g = 0; g < (MCX_K + 15) / 16; ++g)                       \
-            if (flush_rel < 16u && 16u * g + flush_rel < (u32)MCX_K) wave_sums[wave][16u * g + flush_rel] += (double)mine_[g]; \
-    } while (0)
-#else
+    // (Measured and not kept, round 3: the K wave totals by DPP adds on the vector ALU instead of ds_bpermute_b32 on the LDS
+    // pipe, 16 lanes updating the f64 slots at once -- 20 % fewer LDS instructions, no faster: the kernel is bound by VALU
+    // issue and the LDS pipe has slack. profiles/r03_c5_lds_variants.txt; the variant's code is in commit 9b35320.)
 #define MCX_FLUSH_ACC()                                                                     \
     do {                                                                                    \
         _Pragma("unroll") for (int k = 0; k < MCX_K; ++k) {                                 \
@@ -424,7 +392,6 @@ mcx_integrate_kernel(McxIntegrateArgs a) {
             if (lane == 0u) wave_sums[wave][k] += (double)s_;                               \
         }                                                                                   \
     } while (0)
-#endif
 #else
     double sum[MCX_K];
 #pragma unroll
