@@ -229,3 +229,32 @@ def test_one_process_drives_several_devices_through_the_public_api(integrator):
     with pytest.raises(RuntimeError, match="devices"):
         prepared.launch(1000, 1, torch.zeros(1, dtype=torch.float64, device="cuda"))
     assert np.allclose(prepared.run(3_000_001, 5).values, want["normal"][:1], rtol=1e-9, atol=1e-9)
+
+
+def test_the_bench_line_validates_itself_at_two_ranks():
+    """`python bench.py --gpus 2` through its own launcher, two gloo ranks sharing this box's GPU (RCCL refuses two ranks
+    on one device; every other piece of the N > 1 line is the real one): the one JSON line carries the headline, the
+    other BASELINE configs as legs (C2 / C3 weak, C4 / C5 strong) and `self_check` -- an all-reduce of ones = 2, and per
+    config the all-reduced shard sums equal to the whole grid run on rank 0 (C4: accepted-step counts exactly)."""
+    import json
+    import subprocess
+
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device", "--steps", "3",
+                          "--warmup", "1", "--scale", "0.02", "--legs", "c3,c4,c5", "--no-cpu-baseline", "--no-cold", "--prewarm-ms", "0"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-1500:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["name"] == "c2" and line["scaling"] == "weak"
+    assert set(line["configs"]) == {"c3", "c4", "c5"} and not any("error" in leg for leg in line["configs"].values()), line["configs"]
+    assert [line["configs"][c]["scaling"] for c in ("c3", "c4", "c5")] == ["weak", "strong", "strong"]
+    check = line["self_check"]
+    assert check["rccl_sum_of_ones"] == 2.0 and check["rccl_sum_of_ones_ok"]
+    for cfg in ("c2", "c3", "c4", "c5"):
+        c = check["sharded_equals_single"][cfg]
+        assert c["ok"] and c["max_mean_diff_over_scale"] <= 1e-7, (cfg, c)
+    assert check["sharded_equals_single"]["c4"]["accepted_steps_equal"] is True
+    assert len(line["roofline"]["per_rank_kernel_ms"]) == 2
+    for leg in [line] + list(line["configs"].values()):
+        assert leg["value"] > 0 and leg["philox"]["value"] > 0 and set(leg["stream_valid"]) == {"pcg_ref", "philox"}
