@@ -73,7 +73,7 @@ typedef struct McxMcmcArgs {
     McxTableDesc target_logpdf;   // {x, log p}
     McxTableDesc proposal_logpdf; // {x, log q}
     double* partials;           // [gridDim.x][rows]; column MCX_K = accepted-step count
-    // Time segments (host: mcmc_impl; batched independence sampler only): this launch runs steps it_begin .. it_end of
+    // Time segments (host: mcmc_impl; independence sampler with a normal proposal, either stream): this launch runs steps it_begin .. it_end of
     // every chain (1-based, burn-in included; 0 / 0 = all of them). A launch with it_begin > 1 resumes each chain from
     // seg_state[chain - chain_begin] = {x, w}; one with seg_state != null leaves it there at its end. The random streams
     // are functions of (seed, chain, it), so nothing else carries over.

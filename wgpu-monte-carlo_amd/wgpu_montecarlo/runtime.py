@@ -634,8 +634,9 @@ class Engine:
         return res
 
     def set_mcmc_segments(self, n: int) -> None:
-        """Opt-in: MCMC calls of the batched independence sampler as two chain halves on two streams x n step segments
-        (include/mcx.h: mcx_engine_set_mcmc_segments); 0 = one launch per call."""
+        """MCMC calls of the independence sampler (normal proposal) as two chain halves on two streams x n step segments
+        (include/mcx.h: mcx_engine_set_mcmc_segments): SEGMENTS_AUTO (the default) = 8 for launches of >= 1 048 576 chains,
+        0 = always one launch per call, 2..64 = that many whenever the call qualifies."""
         check(load().mcx_engine_set_mcmc_segments(self._h, int(n)))
 
     def set_target_threads(self, n: int) -> None:
