@@ -148,3 +148,30 @@ def test_auto_stream_policy_picks_philox_only_beyond_the_reference_streams_count
     assert small.desc.rng == rt.RNG_PCG_REF and large.desc.rng == rt.RNG_PHILOX and small is not large
     with pytest.raises(ValueError, match="'pcg_ref'.*'philox' or 'auto'"):
         MonteCarloIntegrator.planner(rng="xoshiro")
+
+
+def test_the_committed_issue_model_describes_the_code_objects_this_tree_builds():
+    """profiles/rNN_issue_model.json names modules by the cache key of their code object; bench.py quotes `ops_per_unit` and
+    the modelled cycles only for a module it finds there. Any edit of the device sources changes the keys: this test fails
+    until `python tools/issue_model.py` has been re-run, so the bench line never falls back to stale constants silently."""
+    import json
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "tools"))
+    import baseline_configs as bc
+
+    files = sorted((root / "profiles").glob("r[0-9][0-9]_issue_model.json"))
+    assert files, "no profiles/rNN_issue_model.json"
+    modules = json.loads(files[-1].read_text())["modules"]
+    for rng in ("pcg_ref", "philox"):
+        mc = MonteCarloIntegrator.planner(rng=rng)
+        for name in ("c2", "c3", "c4", "c5"):
+            key = bc.get(name, Distribution).prepare(mc)._plan.module.key
+            assert key in modules, f"{files[-1].name} has no entry for {name} / {rng} ({key}): re-run tools/issue_model.py"
+            entry = modules[key]
+            assert entry["config"] == name and entry["rng"] == rng
+            ops, source = bc.ops_per_unit(name, key)
+            assert ops == entry["survey_weighted_ops_per_unit"] and "this code object" in source
+    assert bc.ops_per_unit("c2")[0] == pytest.approx(22.0) and bc.ops_per_unit("c5", "no-such-key")[0] == bc.OPS_PER_UNIT["c5"]
