@@ -273,9 +273,10 @@ def test_mcmc_time_segments_run_the_same_chains(integrator, segments):
 
 
 def test_full_size_mcmc_calls_are_time_segmented_by_default(integrator):
-    """The default (MCX_SEGMENTS_AUTO): a launch of >= 1 048 576 chains -- two or more rounds of the chip's wave slots, C4's
-    size -- runs as 8 segments x 2 chain halves, smaller ones as one launch; set_mcmc_segments(0) turns it off. Same chains
-    either way: identical accepted-step counts (every accept decision), sums equal up to the regrouping of the f32 blocks."""
+    """The default (MCX_SEGMENTS_AUTO): a launch of >= 131 072 chains -- two waves per SIMD and more; C4's full size and
+    its 2 / 4 / 8-GPU shards -- runs as 8 segments x 2 chain halves, smaller ones as one launch (there the 16 launches cost
+    more than they cover); set_mcmc_segments(0) turns it off. Same chains either way: identical accepted-step counts
+    (every accept decision), sums equal up to the regrouping of the f32 blocks."""
     from wgpu_montecarlo import Distribution
     from wgpu_montecarlo import runtime as rt
 
@@ -286,7 +287,9 @@ def test_full_size_mcmc_calls_are_time_segmented_by_default(integrator):
     auto = integrator.integrate_mcmc(f2, target, proposal, n_steps=301, n_chains=1_048_576, n_burnin=40, seed=5)
     assert (auto.meta["segments"], auto.meta["launches"]) == (8, 16)
     assert auto.meta["n_blocks"] * auto.meta["block"] == 1_048_576          # the workgroups of one segment, both halves
-    small = integrator.integrate_mcmc(f2, target, proposal, n_steps=301, n_chains=524_288, n_burnin=40, seed=5)
+    shard = integrator.integrate_mcmc(f2, target, proposal, n_steps=301, n_chains=131_072, n_burnin=40, seed=5)
+    assert (shard.meta["segments"], shard.meta["launches"]) == (8, 16)
+    small = integrator.integrate_mcmc(f2, target, proposal, n_steps=301, n_chains=65_536 + 256, n_burnin=40, seed=5)
     assert (small.meta["segments"], small.meta["launches"]) == (0, 1)
     eng.set_mcmc_segments(0)
     try:
