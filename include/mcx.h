@@ -143,10 +143,11 @@ int  mcx_engine_set_target_threads(mcx_engine* e, uint32_t physical_threads);
  * covers that (C4: 8.5 -> 8.0 ms with 8 segments). Same chains, same draws, same accept decisions: the streams are
  * functions of (seed, chain, step), the chain state {x, w} travels through a device buffer, every launch adds its own
  * partial sums (the reference issues one dispatch, src/engine.rs:468-525).
- *   MCX_SEGMENTS_AUTO (the default; MCX_MCMC_SEGMENTS overrides it): 8 segments for launches of >= 131 072 chains (two
- *   waves per SIMD and more: 1 048 576 chains 8.55 -> 8.12 ms, 524 288: 4.60 -> 4.13, 131 072: 1.43 -> 1.36), one launch
- *   below (65 536 chains: 0.95 ms in one launch, 1.22 ms cut); 0 or 1: always one launch; 2..64: that many whenever the
- *   call qualifies.
+ *   MCX_SEGMENTS_AUTO (the default; MCX_MCMC_SEGMENTS overrides it): launches of >= 131 072 chains (two waves per SIMD
+ *   and more) run in 8 segments from 1.4e9 chain-steps (~1 ms of work), in 4 from 7e8, else in one launch -- each segment
+ *   costs ~10 us of launches. At 11 000 steps per chain: 1 048 576 chains 8.55 -> 8.12 ms, 524 288: 4.60 -> 4.13, 131 072:
+ *   1.43 -> 1.36; 65 536 chains lose (0.95 -> 1.22 ms), short calls lose (1 048 576 chains x 400 steps: 0.34 -> 0.38 ms).
+ *   0 or 1: always one launch; 2..64: that many whenever the call qualifies.
  * The side stream, its events and the state buffer are kept PER CALLER STREAM (like the per-workgroup partial sums), so
  * segmented calls in flight on different streams of one engine do not share them. */
 #define MCX_SEGMENTS_AUTO 0xFFFFFFFFu

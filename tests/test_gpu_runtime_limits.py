@@ -274,9 +274,10 @@ def test_mcmc_time_segments_run_the_same_chains(integrator, segments):
 
 def test_full_size_mcmc_calls_are_time_segmented_by_default(integrator):
     """The default (MCX_SEGMENTS_AUTO): a launch of >= 131 072 chains -- two waves per SIMD and more; C4's full size and
-    its 2 / 4 / 8-GPU shards -- runs as 8 segments x 2 chain halves, smaller ones as one launch (there the 16 launches cost
-    more than they cover); set_mcmc_segments(0) turns it off. Same chains either way: identical accepted-step counts
-    (every accept decision), sums equal up to the regrouping of the f32 blocks."""
+    its 2 / 4 / 8-GPU shards -- with >= 1.4e9 chain-steps of work runs as 8 segments x 2 chain halves, with >= 7e8 as 4,
+    anything smaller or shorter as one launch (there the launches cost more than they cover); set_mcmc_segments(0) turns
+    it off. Same chains either way: identical accepted-step counts (every accept decision), sums equal up to the
+    regrouping of the f32 blocks."""
     from wgpu_montecarlo import Distribution
     from wgpu_montecarlo import runtime as rt
 
@@ -284,16 +285,16 @@ def test_full_size_mcmc_calls_are_time_segmented_by_default(integrator):
     proposal = Distribution.normal(0.0, 2.0)
     f2 = [lambda x: x, lambda x: x * x]
     eng = integrator._engine
-    auto = integrator.integrate_mcmc(f2, target, proposal, n_steps=301, n_chains=1_048_576, n_burnin=40, seed=5)
+    run = lambda chains, steps, burn: integrator.integrate_mcmc(f2, target, proposal, n_steps=steps, n_chains=chains, n_burnin=burn, seed=5)
+    auto = run(1_048_576, 1301, 40)                                          # 1.41e9 chain-steps
     assert (auto.meta["segments"], auto.meta["launches"]) == (8, 16)
     assert auto.meta["n_blocks"] * auto.meta["block"] == 1_048_576          # the workgroups of one segment, both halves
-    shard = integrator.integrate_mcmc(f2, target, proposal, n_steps=301, n_chains=131_072, n_burnin=40, seed=5)
-    assert (shard.meta["segments"], shard.meta["launches"]) == (8, 16)
-    small = integrator.integrate_mcmc(f2, target, proposal, n_steps=301, n_chains=65_536 + 256, n_burnin=40, seed=5)
-    assert (small.meta["segments"], small.meta["launches"]) == (0, 1)
+    assert (run(131_072, 10_000, 1000).meta["segments"], run(131_072, 5_400, 0).meta["segments"]) == (8, 4)      # 1.44e9, 7.1e8
+    for chains, steps in ((1_048_576, 400), (131_072, 3000), (65_536 + 256, 30_000)):          # short, short, too few chains
+        assert run(chains, steps, 0).meta["launches"] == 1, (chains, steps)
     eng.set_mcmc_segments(0)
     try:
-        one = integrator.integrate_mcmc(f2, target, proposal, n_steps=301, n_chains=1_048_576, n_burnin=40, seed=5)
+        one = run(1_048_576, 1301, 40)
     finally:
         eng.set_mcmc_segments(rt.SEGMENTS_AUTO)
     assert (one.meta["segments"], one.meta["launches"]) == (0, 1)

@@ -635,7 +635,7 @@ class Engine:
 
     def set_mcmc_segments(self, n: int) -> None:
         """MCMC calls of the independence sampler (normal proposal) as two chain halves on two streams x n step segments
-        (include/mcx.h: mcx_engine_set_mcmc_segments): SEGMENTS_AUTO (the default) = 8 for launches of >= 131 072 chains,
+        (include/mcx.h: mcx_engine_set_mcmc_segments): SEGMENTS_AUTO (the default) = 8 (4) for launches of >= 131 072 chains with >= 1.4e9 (7e8) chain-steps of work,
         0 = always one launch per call, 2..64 = that many whenever the call qualifies."""
         check(load().mcx_engine_set_mcmc_segments(self._h, int(n)))
 
