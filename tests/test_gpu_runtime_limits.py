@@ -368,3 +368,46 @@ def test_philox_mcmc_time_segments_run_the_same_chains(segments):
         assert a.meta["rng"] == b.meta["rng"] == "philox"
         assert a.meta["accept_rate"] == b.meta["accept_rate"], case
         assert np.allclose(a.values, b.values, rtol=2e-6, atol=2e-6), (case, a.values, b.values)
+
+
+@pytest.mark.parametrize("env", [{"MCX_POLL_US": "0"}, {"MCX_NO_ZERO_COPY": "1"}, {"MCX_NO_TIMING": "1"},
+                                 {"MCX_POLL_US": "1"}])
+def test_blocking_calls_give_the_same_bits_on_every_result_path(env):
+    """A blocking call's K doubles reach the host in one of three ways: folded straight into pinned host memory and
+    found by polling the per-row tickets (default), the same with the stream's completion signal (MCX_POLL_US=0, or a
+    call that outlasts the polling window: MCX_POLL_US=1 us), or through the device buffer and a copy
+    (MCX_NO_ZERO_COPY=1: what a runtime without mapped host memory gets). Same kernels, same fold order: the same bits."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    code = r"""
+import json, sys
+sys.path[:0] = [%r, %r]
+import numpy as np
+from wgpu_montecarlo import Distribution, MonteCarloIntegrator
+mc = MonteCarloIntegrator()
+f = [lambda x: x, lambda x: x * x, lambda x: x > 0.5]
+out = {}
+out["k1_small"] = mc.integrate(f, Distribution.normal(0.2, 1.3), n_samples=10_000, seed=3).values.tolist()
+out["k1_large"] = mc.integrate(f, Distribution.normal(0.2, 1.3), n_samples=300_000_000, seed=3).values.tolist()
+out["beta"] = mc.integrate(f, Distribution.beta(2.0, 5.0), n_samples=5_000_000, seed=4).values.tolist()
+r = mc.integrate_mcmc(f[:2], Distribution.normal(0.5, 1.0), Distribution.normal(0.0, 2.0), n_steps=500, n_chains=8192, n_burnin=50, seed=5)
+out["mcmc"] = r.values.tolist() + [r.meta["accept_rate"]]
+out["kernel_ms"] = r.meta["kernel_ms"]
+print(json.dumps(out))
+""" % (str(root / "wgpu-monte-carlo_amd"), str(root))
+
+    def run(extra):
+        import os
+
+        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-1500:]
+        return json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+
+    want, got = run({}), run(env)
+    for key in ("k1_small", "k1_large", "beta", "mcmc"):
+        assert got[key] == want[key], (env, key, got[key], want[key])
+    assert (got["kernel_ms"] < 0) == ("MCX_NO_TIMING" in env) and want["kernel_ms"] > 0
