@@ -372,7 +372,7 @@ def test_philox_mcmc_time_segments_run_the_same_chains(segments):
 
 @pytest.mark.parametrize("env", [{"MCX_POLL_US": "0"}, {"MCX_NO_ZERO_COPY": "1"}, {"MCX_NO_TIMING": "1"},
                                  {"MCX_POLL_US": "1"}])
-def test_blocking_calls_give_the_same_bits_on_every_result_path(env):
+def test_blocking_calls_give_the_same_bits_on_every_result_path(env, tmp_path):
     """A blocking call's K doubles reach the host in one of three ways: folded straight into pinned host memory and
     found by polling the per-row tickets (default), the same with the stream's completion signal (MCX_POLL_US=0, or a
     call that outlasts the polling window: MCX_POLL_US=1 us), or through the device buffer and a copy
@@ -400,10 +400,13 @@ out["kernel_ms"] = r.meta["kernel_ms"]
 print(json.dumps(out))
 """ % (str(root / "wgpu-monte-carlo_amd"), str(root))
 
+    script = tmp_path / "result_paths.py"               # a file: lambdas are lowered from their source text
+    script.write_text(code)
+
     def run(extra):
         import os
 
-        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
+        res = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stderr[-1500:]
         return json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
 
