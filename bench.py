@@ -375,6 +375,35 @@ def sharded_equals_single(ctx, wl, prepared, n_step, n_eff):
     return d
 
 
+def shard_timings(ctx, wl, prepared, nominal, scaling, one_gpu_ms, reps=8):
+    """N = 1 only: what each rank of a 2 / 4 / 8-GPU run of this config would launch -- the shard (rank 0 and the last rank of
+    N) of the step that run takes (weak: N x the nominal size; strong: the nominal size) -- timed on THIS GPU with
+    `launch(..., shard=(r, N))`. Not a multi-GPU measurement: it leaves out the all-reduce of K doubles (latency-bound,
+    overlapped with the next step) and assumes N GPUs like this one; it is the per-rank kernel time a real run cannot
+    beat, in the driver's own record even when no 8-GPU node is available to it."""
+    torch = ctx.torch
+    out = torch.zeros(wl.rows, dtype=torch.float64, device=ctx.device)
+    table = {}
+    for n in (2, 4, 8):
+        n_step = int(nominal) * (n if scaling == "weak" else 1)
+        worst = 0.0
+        for r in (0, n - 1):
+            wl.launch(prepared, n_step, 7, out, shard=(r, n))
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for j in range(reps):
+                wl.launch(prepared, n_step, 100 + j, out, shard=(r, n))
+            e1.record()
+            torch.cuda.synchronize()
+            worst = max(worst, e0.elapsed_time(e1) / reps)
+        table[str(n)] = dict(slowest_shard_ms=worst,
+                             expected_speedup=(n * one_gpu_ms / worst) if scaling == "weak" else (one_gpu_ms / worst))
+    table["note"] = ("single-GPU timings of the shards an N-GPU run launches (rank 0 and rank N-1), no collective: an expectation, "
+                     "not a multi-GPU measurement")
+    return table
+
+
 def measure_config(ctx, name, steps, warmup, primary, cpu_seconds):
     """One BASELINE config through the same timed loop: reference stream, Philox stream, the dominant kernel's time and
     roofline, the blocking API call, the N > 1 self-check, the CPU baseline. Returns the leg's dict (rank 0) or None."""
@@ -473,6 +502,7 @@ def measure_config(ctx, name, steps, warmup, primary, cpu_seconds):
     hbm_gbps = hbm_bytes / (kernel_ms * 1e-3) / 1e9
 
     check = sharded_equals_single(ctx, wl, prepared, n_step, n_eff) if world > 1 else None
+    shards = shard_timings(ctx, wl, prepared, nominal * args.scale, scaling, kernel_ms) if (world == 1 and not under_profiler()) else None
 
     # blocking Python-API latency for the same call (plan-cache lookup + launch + the K doubles back), rank-local
     api = None
@@ -564,6 +594,8 @@ def measure_config(ctx, name, steps, warmup, primary, cpu_seconds):
     }
     if check is not None:
         leg["sharded_equals_single"] = check
+    if shards is not None:
+        leg["shard_timings"] = shards
     if api:
         leg.update(api)
     if not args.no_cpu_baseline and world == 1:
