@@ -153,7 +153,8 @@ int  mcx_engine_set_target_threads(mcx_engine* e, uint32_t physical_threads);
 #define MCX_SEGMENTS_AUTO 0xFFFFFFFFu
 int  mcx_engine_set_mcmc_segments(mcx_engine* e, uint32_t segments);
 /* The default: workgroups a launch of `samples` samples aims for when each workgroup stages `lds_bytes` of tables --
- * 4096 (16 per CU) once every workgroup samples at least 6 samples per staged byte, never fewer than 2^20 / block. */
+ * 4096 (16 per CU) once every workgroup samples at least 6 samples per staged byte, never fewer than 2^20 / block, and in
+ * whole rounds of what the chip holds at once (256 CUs x min(2048 / block, 160 KiB / staged bytes) workgroups). */
 uint32_t mcx_default_launch_blocks(uint64_t samples, uint32_t lds_bytes, uint32_t block);
 
 /* ------------------------------------------------------------------------------------------

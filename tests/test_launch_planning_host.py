@@ -80,11 +80,13 @@ def test_unbounded_or_degenerate_ranges_are_refused():
 
 def test_default_launch_geometry():
     """Workgroups per launch (mcx_default_launch_blocks): 4096 without staged tables; with tables one workgroup per
-    6 x lds_bytes samples, clamped to [2^20 / block, 4096] (profiles/r02b_launch_geometry_vs_call_size.txt)."""
+    6 x lds_bytes samples, clamped to [2^20 / block, 4096] (profiles/r02b_launch_geometry_vs_call_size.txt), in whole
+    rounds of the workgroups the chip holds at once (round 3: 2880 workgroups = 5.6 rounds were 5 % slower than 2560 = 5)."""
     f = rt.default_launch_blocks
     assert f(10**9, 0, 256) == 4096 and f(10**3, 0, 256) == 4096            # the unit count caps it later (plan_integrate)
     assert f(10**7, 73728, 1024) == 1024 and f(3 * 10**8, 73728, 1024) == 1024
-    assert f(10**9, 73728, 1024) == 10**9 // (6 * 73728) == 2260
+    assert 10**9 // (6 * 73728) == 2260 and f(10**9, 73728, 1024) == 2048      # 4 whole rounds of 512 resident workgroups
+    assert f(1_250_000_000, 73728, 1024) == 2560                                 # C5's 8-GPU shard: 2825 -> 5 rounds
     assert f(3 * 10**9, 73728, 1024) == 4096 and f(10**10, 73728, 1024) == 4096
     assert f(10**8, 17920, 512) == 2048 and f(10**9, 17920, 512) == 4096
     assert f(10**9, 0, 64) == 16384                                          # small workgroups: never below 2^20 threads
