@@ -15,6 +15,7 @@ T*L, MCMC `n_samples = n_chains * n_steps`). Underneath, nothing is shared with 
 from __future__ import annotations
 
 import os
+import threading
 from typing import Callable, List, Optional, Sequence, Union
 
 import numpy as np
@@ -79,6 +80,7 @@ def _distribution_key(d: Distribution):
 
 
 _PLAN_CACHE_ENTRIES = 128
+_PLAN_CACHE_LOCK = threading.Lock()
 
 # Tuning knobs read while a plan is built (here, in runtime.make_desc and in libmcx's source assembly): part of the plan
 # key, so flipping one at run time (A/B scripts, tests) is not answered from the cache.
@@ -364,9 +366,10 @@ class MonteCarloIntegrator:
         if hit is not None:
             return hit[0]
         plan = build()
-        if len(cache) >= _PLAN_CACHE_ENTRIES:
-            cache.pop(next(iter(cache)))             # oldest entry (dicts keep insertion order)
-        cache[key] = (plan, tuple(functions), tuple(dists))      # the strong references keep the id()s in the key valid
+        with _PLAN_CACHE_LOCK:                       # host threads may share an engine: lookups are lock-free, updates are not
+            while len(cache) >= _PLAN_CACHE_ENTRIES:
+                cache.pop(next(iter(cache)))         # oldest entry (dicts keep insertion order)
+            cache[key] = (plan, tuple(functions), tuple(dists))  # the strong references keep the id()s in the key valid
         return plan
 
     # ---- helpers ---------------------------------------------------------------------------------
