@@ -554,6 +554,7 @@ class Engine:
         self._modules = {}
         self._tables = {}
         self._plans = {}               # api._cached_plan: compiled plans of repeat calls (hold modules + tables)
+        self._cache_lock = threading.Lock()      # module / table caches: host threads may share an engine
         _live_engines.add(self)        # closed at interpreter exit while the HIP runtime is still fully alive
 
     @classmethod
@@ -583,14 +584,13 @@ class Engine:
         keys = np.ascontiguousarray(keys, dtype=np.float32)
         values = np.ascontiguousarray(values, dtype=np.float32)
         key = (kind, keys.tobytes(), values.tobytes())
-        tb = self._tables.get(key)
-        if tb is None:
-            while len(self._tables) >= 64:
-                self._tables.pop(next(iter(self._tables)))            # oldest first; in-use tables stay referenced by plans
-            tb = Table(self, kind, keys, values)
-        else:
-            del self._tables[key]
-        self._tables[key] = tb
+        with self._cache_lock:
+            tb = self._tables.pop(key, None)
+            if tb is None:
+                while len(self._tables) >= 64:
+                    self._tables.pop(next(iter(self._tables)))        # oldest first; in-use tables stay referenced by plans
+                tb = Table(self, kind, keys, values)
+            self._tables[key] = tb                                    # (re-)insert as the most recent
         return tb
 
     MAX_MODULES = 256
@@ -600,12 +600,13 @@ class Engine:
         when its last user drops it (plans / prepared integrands hold references), and mcx_module_release waits for
         the module's last launch before it unloads the code object."""
         key = (user_src, bytes(desc))
-        mod = self._modules.pop(key, None)
-        if mod is None:
-            mod = Module(self, user_src, desc)
-            while len(self._modules) >= self.MAX_MODULES:
-                self._modules.pop(next(iter(self._modules)))         # dicts keep insertion order: the oldest entry
-        self._modules[key] = mod                                      # (re-)insert as the most recent
+        with self._cache_lock:
+            mod = self._modules.pop(key, None)
+            if mod is None:
+                mod = Module(self, user_src, desc)
+                while len(self._modules) >= self.MAX_MODULES:
+                    self._modules.pop(next(iter(self._modules)))     # dicts keep insertion order: the oldest entry
+            self._modules[key] = mod                                  # (re-)insert as the most recent
         return mod
 
     def table(self, kind: int, keys, values) -> Table:
