@@ -193,6 +193,31 @@ def test_math_modes_agree(mc):
     assert np.allclose(vals["fast"], vals["precise"], atol=2e-5)
 
 
+def test_default_trig_and_pow_stay_within_their_stated_error_on_wide_arguments():
+    """math="default" compiles sin / cos / tan to the range-reduced hardware instructions and pow to exp2(y log2|x|)
+    (device/mcx_device.hpp mcx_sin .. mcx_pow). Mean absolute differences are compared sample by sample with "precise"
+    (ocml) on the same counter stream: arguments from a few to 1e5 radians, past the 1e6 switch to ocml, negative bases
+    with integral and fractional exponents. The pointwise bounds are in profiles/r03_trig_pow_accuracy.txt."""
+    from wgpu_montecarlo import MonteCarloIntegrator
+
+    def identities(scale):
+        return [lambda x: np.abs(math.sin(scale * x) ** 2 + math.cos(scale * x) ** 2 - 1.0),
+                lambda x: math.sin(scale * x), lambda x: math.cos(scale * x),
+                lambda x: math.cos(scale * x) * math.tan(scale * x) - math.sin(scale * x)]
+
+    for scale, dist in ((1.0, D().uniform(-10.0, 10.0)), (1000.0, D().uniform(-100.0, 100.0)), (3.0e6, D().uniform(-1.0, 1.0))):   # uniform: the same samples in both modes
+        got = {m: MonteCarloIntegrator(math=m).integrate(identities(scale), dist, n_samples=1_000_000, seed=9).values for m in ("precise", "default")}
+        assert got["default"][0] < 1.5e-6, (scale, got)                       # mean |sin^2 + cos^2 - 1|: two errors of <= 4e-7 each, doubled
+        assert np.allclose(got["default"][1:3], got["precise"][1:3], atol=5e-7), (scale, got)
+        assert abs(got["default"][3]) < 2e-6, (scale, got)
+    powers = [lambda x: np.abs(x) ** 2.5, lambda x: x ** (2.0 + 0.0 * x), lambda x: x ** (3.0 + 0.0 * x), lambda x: (1.0 + x * x) ** (-0.75),
+              lambda x: 2.0 ** x, lambda x: np.abs(x) ** 0.5, lambda x: x ** (0.0 * x), lambda x: (0.0 * x) ** (x * x)]
+    got = {m: MonteCarloIntegrator(math=m).integrate(powers, D().uniform(-4.0, 5.0), n_samples=1_000_000, seed=9).values for m in ("precise", "default")}
+    assert np.all(np.isfinite(got["precise"])) and np.allclose(got["default"], got["precise"], rtol=3e-6, atol=1e-7), got
+    r = MonteCarloIntegrator().integrate([lambda x: x ** 0.5], D().normal(0.0, 1.0), n_samples=100_000)
+    assert np.isnan(r.values[0])                                                # fractional power of a negative base, as powf
+
+
 def test_std_error_output():
     """std_error=True (extension): sum (f w)^2 accumulated in the same pass; standard errors match theory."""
     from wgpu_montecarlo import MonteCarloIntegrator

@@ -478,6 +478,42 @@ MCX_DEV float mcx_smoothstep(float lo, float hi, float x) {
     return t * t * (3.0f - 2.0f * t);
 }
 MCX_DEV float mcx_select(float f, float t, bool c) { return c ? t : f; }
+
+// sin / cos / tan / pow of math="default" (emit_hip.py): the hardware instructions behind an argument reduction
+// that keeps their error flat. v_sin_f32 / v_cos_f32 take revolutions; x / 2pi is formed as n + phase with
+// n = rint(x * c_hi) and phase = fma(x, c_lo, fma(x, c_hi, -n)) (c_hi + c_lo = 1/2pi to 2^-52, the inner fma is the
+// exact product less n), so the phase lies in [-0.5, 0.5] and is good to 2^-25 revolutions whatever |x| is, and
+// small arguments keep their relative accuracy. Measured over 2^24 points per range (tools/ubench/trig_accuracy.hip,
+// profiles/r03_trig_pow_accuracy.txt): absolute error <= 2.6e-7 for |x| <= 128 and <= 4e-7 up to 1e6, against 7e-8 for
+// ocml and the 4.9e-4 WGSL promises on [-pi, pi]; 77 against 146 cycles per wave for a (sin, cos) pair, the range check
+// included. From 1e6 on (where consecutive floats are 0.06 rad apart and more) the ocml routine runs.
+MCX_DEV float mcx_trig_phase(float x) {
+    const float c_hi = 0x1.45f306p-3f, c_lo = 0x1.b9391p-28f;
+    const float n = __builtin_rintf(x * c_hi);
+    return __builtin_fmaf(x, c_lo, __builtin_fmaf(x, c_hi, -n));
+}
+#define MCX_TRIG_HW_BOUND 1.0e6f
+MCX_DEV float mcx_sin(float x) { return fabsf(x) < MCX_TRIG_HW_BOUND ? __builtin_amdgcn_sinf(mcx_trig_phase(x)) : sinf(x); }
+MCX_DEV float mcx_cos(float x) { return fabsf(x) < MCX_TRIG_HW_BOUND ? __builtin_amdgcn_cosf(mcx_trig_phase(x)) : cosf(x); }
+MCX_DEV float mcx_tan(float x) {
+    if (!(fabsf(x) < MCX_TRIG_HW_BOUND)) return tanf(x);
+    const float ph = mcx_trig_phase(x);
+    return __builtin_amdgcn_sinf(ph) * __builtin_amdgcn_rcpf(__builtin_amdgcn_cosf(ph));
+}
+// pow as WGSL defines its accuracy, exp2(y * log2(x)) on v_log_f32 / v_exp_f32 (relative error about
+// 1.2e-7 * (1 + |y * log2 x|); 40 against 600 cycles per wave for ocml powf), with powf's results for a negative
+// base: an integral exponent carries the sign of its parity, any other gives NaN. Zeros, denormals, infinities
+// and NaNs in either argument take the ocml routine.
+MCX_DEV float mcx_pow(float x, float y) {
+    const float ax = fabsf(x);
+    if (!(ax >= 0x1p-126f && ax < __builtin_inff() && fabsf(y) < __builtin_inff())) return powf(x, y);
+    float r = __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(ax));
+    if (x < 0.0f) {
+        const float h = 0.5f * y;
+        r = (truncf(y) != y) ? __builtin_nanf("") : ((truncf(h) != h) ? -r : r);
+    }
+    return r;
+}
 MCX_DEV float mcx_degrees(float r) { return r * 57.29577951308232f; }
 MCX_DEV float mcx_radians(float d) { return d * 0.017453292519943295f; }
 // WGSL `%`: truncated remainder for floats (fmodf), the C operator for integers

@@ -119,7 +119,7 @@ def functions_to_hip(functions: Sequence[FunctionLike], math="default") -> str:
             key = (getattr(fn, "__code__", None), name, math, tuple(ir_fn.consts.items()))
             parts.append(_emit_cached(key, lambda: emit_hip.emit_function(ir_fn, name, math)))
         elif isinstance(fn, str):
-            parts.append(_emit_cached((fn, i, "wgsl"), lambda: wgsl_to_hip.translate(fn, i, f"user_func_{i}")))
+            parts.append(_emit_cached((fn, i, "wgsl", math), lambda: wgsl_to_hip.translate(fn, i, f"user_func_{i}", math)))
         else:
             raise TypeError(f"Function must be callable or WGSL string, got {type(fn)}")
     return "\n\n".join(parts)

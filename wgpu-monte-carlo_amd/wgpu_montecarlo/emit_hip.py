@@ -48,16 +48,22 @@ _ARITY = {"min": 2, "max": 2, "clamp": 3, "mix": 3, "step": 2, "smoothstep": 3, 
 # math modes (MonteCarloIntegrator(math=...)):
 #   "precise": ocml functions and IEEE division everywhere.
 #   "default": exp / log / sqrt / division use the hardware instructions (v_exp_f32, v_log_f32, v_sqrt_f32,
-#              v_rcp_f32: 1-2 ulp, exp degrading like 2|x| ulp). That is inside the accuracy WGSL itself
-#              promises for these operations (division 2.5 ulp, exp 3 + 2|x| ulp, log 3 ulp, sqrt via
-#              inverseSqrt 2 ulp), i.e. inside what the reference's own backends deliver. sin / cos / tan /
-#              pow keep the ocml versions because their hardware forms are only valid on a bounded domain.
-#   "fast":    additionally __sinf / __cosf / __tanf (argument range |x| < ~1600).
+#              v_rcp_f32: 1-2 ulp, exp degrading like 2|x| ulp); sin / cos / tan use v_sin_f32 / v_cos_f32 behind a
+#              two-constant argument reduction (absolute error <= 4e-7 for |x| < 1e6, ocml beyond: device/mcx_device.hpp
+#              mcx_sin) and pow is exp2(y * log2|x|) with powf's sign and NaN rules (relative error about
+#              1.2e-7 * (1 + |y log2 x|), mcx_pow). All of it is inside the accuracy WGSL itself promises for these
+#              operations (division 2.5 ulp, exp 3 + 2|x| ulp, log 3 ulp, sqrt via inverseSqrt 2 ulp, sin / cos 2^-11
+#              absolute on [-pi, pi], pow "as exp2(y * log2 x)"), i.e. inside what the reference's own backends deliver.
+#              Measured: profiles/r03_trig_pow_accuracy.txt.
+#   "fast":    sin / cos / tan as __sinf / __cosf / __tanf: one multiply and the instruction, the error grows
+#              like 7e-8 * |x| and the argument range is |x| < ~1600.
 _NATIVE_FUNCS = {
     "exp": "__expf({0})", "exp2": "__builtin_amdgcn_exp2f({0})", "log": "__logf({0})",
     "log2": "__builtin_amdgcn_logf({0})", "sqrt": "__builtin_amdgcn_sqrtf({0})",
 }
-_FAST_FUNCS = dict(_NATIVE_FUNCS, sin="__sinf({0})", cos="__cosf({0})", tan="__tanf({0})")
+_DEFAULT_FUNCS = dict(_NATIVE_FUNCS, sin="mcx_sin({0})", cos="mcx_cos({0})", tan="mcx_tan({0})",
+                      pow="mcx_pow({0}, {1})", power="mcx_pow({0}, {1})")
+_FAST_FUNCS = dict(_DEFAULT_FUNCS, sin="__sinf({0})", cos="__cosf({0})", tan="__tanf({0})")
 MATH_MODES = ("precise", "default", "fast")
 
 _CONST_VALUES = {
@@ -106,7 +112,7 @@ class _HipPrinter:
     def __init__(self, math, consts=None) -> None:
         self.consts = consts or {}
         self.mode = _mode(math)
-        self.table = {"precise": {}, "default": _NATIVE_FUNCS, "fast": _FAST_FUNCS}[self.mode]
+        self.table = {"precise": {}, "default": _DEFAULT_FUNCS, "fast": _FAST_FUNCS}[self.mode]
 
     def expr(self, node) -> str:
         if isinstance(node, ir.Num):
@@ -141,7 +147,7 @@ class _HipPrinter:
                 if sign > 0:
                     return chain
                 return f"(1.0f / {chain})" if self.mode == "precise" else f"mcx_div(1.0f, {chain})"
-            return f"powf({base}, {self.expr(node.exponent)})"
+            return self.table.get("pow", _FUNCS["pow"]).format(base, self.expr(node.exponent))
         if isinstance(node, ir.Unary):
             return f"({node.op}{self.expr(node.operand)})"
         if isinstance(node, ir.Cmp):

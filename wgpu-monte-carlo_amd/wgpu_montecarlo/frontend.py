@@ -237,10 +237,11 @@ def _parse_fragment(text: str) -> Optional[ast.AST]:
     while found != -1:
         tail = stripped[found:]
         for end in range(len(tail), 6, -1):
-            try:
-                return ast.parse(tail[:end].rstrip(",) \n]"), mode="exec")
-            except SyntaxError:
-                continue
+            for cut in (tail[:end].rstrip(", \n"), tail[:end].rstrip(",) \n]")):     # keep the brackets the lambda itself closes
+                try:
+                    return ast.parse(cut, mode="exec")
+                except SyntaxError:
+                    continue
         found = stripped.find("lambda", found + 1)
     return None
 

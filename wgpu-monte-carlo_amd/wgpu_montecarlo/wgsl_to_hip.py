@@ -42,6 +42,15 @@ _BUILTINS = {
     "degrees": "mcx_degrees", "radians": "mcx_radians",
 }
 
+# math modes of emit_hip.py applied to the float-only builtins ("precise", the default here, leaves the ocml routines above):
+# the hardware exp / log / sqrt, the range-reduced hardware sin / cos / tan and exp2(y log2|x|) for pow (device/mcx_device.hpp)
+_MATH_BUILTINS = {
+    "precise": {},
+    "default": {"sin": "mcx_sin", "cos": "mcx_cos", "tan": "mcx_tan", "pow": "mcx_pow", "exp": "__expf", "exp2": "__builtin_amdgcn_exp2f",
+                "log": "__logf", "log2": "__builtin_amdgcn_logf", "sqrt": "__builtin_amdgcn_sqrtf"},
+}
+_MATH_BUILTINS["fast"] = dict(_MATH_BUILTINS["default"], sin="__sinf", cos="__cosf", tan="__tanf")
+
 _BINARY_LEVELS: List[Tuple[str, ...]] = [
     ("||",), ("&&",), ("|",), ("^",), ("&",), ("==", "!="), ("<", ">", "<=", ">="), ("<<", ">>"),
     ("+", "-"), ("*", "/", "%"),
@@ -82,11 +91,14 @@ def _number(text: str) -> str:
 
 
 class _Parser:
-    def __init__(self, tokens, slot: int) -> None:
+    def __init__(self, tokens, slot: int, math: str = "precise") -> None:
         self.toks = tokens
         self.i = 0
         self.slot = slot
         self.local_functions: List[str] = []
+        if math not in _MATH_BUILTINS:
+            raise ValueError(f"math must be one of {tuple(_MATH_BUILTINS)}")
+        self.builtins = dict(_BUILTINS, **_MATH_BUILTINS[math])
 
     # ---- token helpers ----
     def peek(self, k: int = 0):
@@ -178,8 +190,8 @@ class _Parser:
                 if len(args) != 3:
                     raise TranspilerError("WGSL function string: select() takes three arguments")
                 return f"(({args[2]}) ? ({args[1]}) : ({args[0]}))"
-            if value in _BUILTINS:
-                return f"{_BUILTINS[value]}({', '.join(args)})"
+            if value in self.builtins:
+                return f"{self.builtins[value]}({', '.join(args)})"
             if value in _TABLE_CALLS and value not in self.local_functions:
                 return f"{_TABLE_CALLS[value]}({', '.join(args)})"
             if value in self.local_functions:
@@ -223,7 +235,7 @@ class _Parser:
         target = self.ident()
         if self.accept("("):
             args = self.call_args()
-            callee = _BUILTINS.get(target) or self.fn_name(target)
+            callee = self.builtins.get(target) or self.fn_name(target)
             return f"{callee}({', '.join(args)})"
         kind, op = self.take()
         if op in ("++", "--"):
@@ -319,12 +331,14 @@ class _Parser:
         return original, text
 
 
-def translate(wgsl: str, slot: int, entry_name: str) -> str:
-    """Translate one WGSL function string (entry function first, optional helpers after it)."""
+def translate(wgsl: str, slot: int, entry_name: str, math: str = "precise") -> str:
+    """Translate one WGSL function string (entry function first, optional helpers after it). `math` selects the
+    routines behind exp / log / sqrt / sin / cos / tan / pow as in emit_hip.py; `/` stays the C operator in every mode
+    (the translator does not type expressions, and an integer quotient must stay one)."""
     tokens = _tokenize(wgsl)
     if not tokens:
         raise TranspilerError("empty WGSL function string")
-    parser = _Parser(tokens, slot)
+    parser = _Parser(tokens, slot, math)
     # pre-scan helper names so that calls are prefixed consistently
     names = [tokens[j + 1][1] for j in range(len(tokens) - 1) if tokens[j] == ("id", "fn") and tokens[j + 1][0] == "id"]
     if not names:
