@@ -214,3 +214,22 @@ def test_error_mapping(core):
         core.integrate_mcmc(["fn f(x: f32) -> f32 { return x; }"], "normal", {}, "normal", {}, 0, 10, 0, 1)
     with pytest.raises(RuntimeError):
         core.integrate(["fn f(x: f32) -> f32 { return nope(x); }"], "normal", {}, 1000, 1)
+
+
+def test_the_binding_takes_a_math_mode(core, monkeypatch):
+    """`math` (and MCX_CORE_MATH for callers that cannot pass it) selects the routines behind the WGSL builtins of the
+    function strings; the default stays ocml. Uniform sampling: the same samples in every mode."""
+    from wgpu_montecarlo import _core
+
+    texts = ["fn f(x: f32) -> f32 { return x / (exp(sin(x)) + 2.0 + cos(exp(x))); }",
+             "fn g(x: f32) -> f32 { return pow(abs(x), 1.5) + tan(0.3 * x) + sqrt(abs(x)) * log(1.0 + x * x); }"]
+    args = (texts, "uniform", {"min": -3.0, "max": 3.0}, 1_000_000, 11)
+    precise = core.integrate(*args)
+    assert np.array_equal(precise, _core.MonteCarloIntegrator(math="precise").integrate(*args))
+    default = _core.MonteCarloIntegrator(math="default").integrate(*args)
+    assert np.allclose(default, precise, rtol=0, atol=2e-6) and not np.array_equal(default, precise)
+    monkeypatch.setenv("MCX_CORE_MATH", "default")
+    assert np.array_equal(_core.MonteCarloIntegrator().integrate(*args), default)
+    assert np.allclose(_core.MonteCarloIntegrator(math="fast").integrate(*args), precise, rtol=0, atol=5e-6)
+    with pytest.raises(ValueError):
+        _core.MonteCarloIntegrator(math="quick")

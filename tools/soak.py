@@ -35,7 +35,8 @@ def free_device_mb():
 
 def make_fn(c):
     # a new constant gives a new code object key -> a new module; the body stays in the emitter's subset
-    return [lambda x, c=c: x * c, lambda x, c=c: x * x + c, lambda x, c=c: math.sin(x * c), lambda x, c=c: math.exp(-x * x * c)]
+    return [lambda x, c=c: x * c, lambda x, c=c: x * x + c, lambda x, c=c: math.sin(x * c), lambda x, c=c: math.exp(-x * x * c),
+            lambda x, c=c: np.abs(x) ** (c + 0.5) + math.cos(3.0 * x)]
 
 
 def main():
@@ -50,7 +51,7 @@ def main():
         kind = int(rng.integers(0, 13))
         mc = MonteCarloIntegrator(target_threads=int(rng.choice([256, 4096, 65536])), rng=str(rng.choice(["pcg_ref", "philox"])),
                                   std_error=bool(rng.integers(0, 2)))
-        fns = make_fn(float(rng.integers(1, 40)) / 8.0)[: int(rng.integers(1, 5))]
+        fns = make_fn(float(rng.integers(1, 40)) / 8.0)[: int(rng.integers(1, 6))]
         n = int(rng.choice([1000, 100_000, 3_000_000, 50_000_000]))
         if kind == 0:
             r = mc.integrate(fns, Distribution.normal(float(rng.normal()), 0.5 + float(rng.random())), n_samples=n, seed=calls)

@@ -15,6 +15,7 @@ libmcx's (include/mcx.h).
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -72,15 +73,22 @@ def _f32(a) -> Optional[np.ndarray]:
 class MonteCarloIntegrator:
     """Replaces `_core.MonteCarloIntegrator` (src/lib.rs:17-431)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, math: Optional[str] = None):
+        """`math` (an extension; the reference's constructor takes nothing): the routines behind the WGSL builtins exp /
+        log / sqrt / sin / cos / tan / pow of the function strings, as in emit_hip.py -- "precise" (the default here: ocml,
+        what the parity tests of this binding hold), "default" (the hardware instructions, inside WGSL's own accuracy
+        bounds: the reference's benchmark integrand runs 2.8x faster) or "fast". MCX_CORE_MATH sets it for callers that
+        cannot pass it, such as the reference's unmodified __init__.py."""
         self._engine = runtime.Engine.shared(device)           # RuntimeError("Failed to initialize GPU: ...")
+        self._math = math if math is not None else os.environ.get("MCX_CORE_MATH", "precise")
+        if self._math not in ("precise", "default", "fast"):
+            raise ValueError("math must be one of ('precise', 'default', 'fast')")
 
     # ---- helpers ----------------------------------------------------------------------------------
-    @staticmethod
-    def _source(functions: Sequence[str]) -> str:
+    def _source(self, functions: Sequence[str]) -> str:
         if len(functions) == 0:
             raise ValueError("At least one function is required")          # src/lib.rs:61-65
-        return "\n\n".join(wgsl_to_hip.translate(text, i, f"user_func_{i}") for i, text in enumerate(functions))
+        return "\n\n".join(wgsl_to_hip.translate(text, i, f"user_func_{i}", self._math) for i, text in enumerate(functions))
 
     def _cdf(self, dist_type: str, x_table, cdf_table):
         if dist_type != "custom":
