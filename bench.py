@@ -22,9 +22,12 @@ command times ALL of them: c2 is the headline (`value`), c3 / c4 / c5 run throug
 and are reported under `configs` in the same JSON line (--legs), each with its own kernel time, roofline, accuracy on
 both streams and a short CPU-baseline slice. At N > 1 the line also carries `self_check`: an RCCL all-reduce of ones
 (= N) and, per config, the all-reduced shard sums against the whole grid run on rank 0 (`sharded_equals_single`).
+At N = 1 it ends with `reference_protocol`: the reference's own benchmark (examples/benchmark.py: wall clock around blocking
+integrate() calls of x / (exp(sin x) + cos(exp x)) on N(0,1)) at n = 1e3 / 1e5 / 1e7 / 1e9.
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -658,6 +661,40 @@ def cpu_baseline_numpy(target_seconds):
                 mean_error_vs_truth=[float(v) for v in (sums / n_eff - np.array([0.0, 1.0, 0.0, 3.0]))])
 
 
+def protocol_integrand(x):
+    return x / (math.exp(math.sin(x)) + math.cos(math.exp(x)))
+
+
+def reference_protocol(ctx):
+    """The reference's own benchmark (examples/benchmark.py:8-68) on this GPU, N = 1: wall clock around the blocking
+    `integrate([f], Normal(0,1), n)` for f(x) = x / (exp(sin x) + cos(exp x)), one warm-up call at n = 1000, at the smallest,
+    a middle and the largest size of its list (1e3, 1e5, 1e7) and at 1e9; beside it the kernel time, and the single-core numpy
+    evaluation the reference compares itself with (vectorised here -- the reference's per-element loop is 100x slower), at 1e7.
+    The reference's call recompiles its shader every time (src/engine.rs:325-331); here the first call of a process compiles or
+    loads the code object (`first_call_ms`) and the others find it cached."""
+    np = ctx.np
+    f = protocol_integrand
+    mc = ctx.MonteCarloIntegrator(device=ctx.local_rank)
+    dist_n = ctx.Distribution.normal(0.0, 1.0)
+    t0 = time.perf_counter()
+    mc.integrate([f], dist_n, n_samples=1000)
+    out = {"integrand": "x / (exp(sin x) + cos(exp x)) on N(0,1), examples/benchmark.py of the reference", "math": "default",
+           "first_call_ms": (time.perf_counter() - t0) * 1e3, "calls": []}
+    for n in (1_000, 100_000, 10_000_000, 1_000_000_000):
+        times = []
+        for _ in range(12):
+            t0 = time.perf_counter()
+            res = mc.integrate([f], dist_n, n_samples=n)
+            times.append((time.perf_counter() - t0) * 1e3)
+        out["calls"].append({"n_samples": n, "n_eff": res.meta["n_eff"], "call_ms": float(np.median(times[2:])), "kernel_ms": res.meta["kernel_ms"],
+                             "samples_per_s": res.meta["n_eff"] / (float(np.median(times[2:])) * 1e-3), "value": float(res.values[0])})
+    xs = np.random.default_rng(0).standard_normal(10_000_000).astype(np.float32)
+    t0 = time.perf_counter()
+    float(np.mean(xs / (np.exp(np.sin(xs)) + np.cos(np.exp(xs)))))
+    out["numpy_vectorised_1core_ms_at_1e7"] = (time.perf_counter() - t0) * 1e3
+    return out
+
+
 def leg_names(args):
     """BASELINE configs timed next to the headline in the same line (the driver only ever runs the default command)."""
     if args.legs == "none":
@@ -719,6 +756,12 @@ def run_rank(args):
             legs[name] = measure_config(ctx, name, min(args.steps, args.leg_steps), min(args.warmup, 3), False, args.leg_cpu_seconds)
         except Exception as exc:                     # noqa: BLE001 -- the headline must survive a broken leg
             legs[name] = {"error": f"{type(exc).__name__}: {exc}"[:600]}
+    protocol = None
+    if world == 1 and legs and not under_profiler():
+        try:
+            protocol = reference_protocol(ctx)
+        except Exception as exc:                         # noqa: BLE001
+            protocol = {"error": f"{type(exc).__name__}: {exc}"[:600]}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -734,6 +777,7 @@ def run_rank(args):
             "collective_backend": args.backend if world > 1 else None,
             "cold": cold,
             "configs": legs,
+            "reference_protocol": protocol,
             "self_check": None if world == 1 else {
                 "rccl_sum_of_ones": rccl_sum_of_ones,
                 "rccl_sum_of_ones_ok": rccl_sum_of_ones == float(world),
@@ -798,6 +842,7 @@ def prewarm_cache():
                 for parts in (2, 4, 8):             # a rank's share of 1 048 576 chains picks its workgroup size
                     prepared._select(wl.nominal, shard=(0, parts))
                     built[(name, rng, parts)] = prepared._plan.module.key
+    built["reference_protocol"] = MonteCarloIntegrator.planner().prepare_integrate([protocol_integrand], Distribution.normal(0.0, 1.0))._plan.module.key
     return built
 
 
