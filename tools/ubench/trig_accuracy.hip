@@ -24,8 +24,27 @@ __device__ __forceinline__ float phase(float x) {
     return __builtin_amdgcn_fractf(p) + r;                   // whole revolutions dropped before the low part is added
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float g_expect(float x, int c) {          // guard variant: the slow path marked unlikely
+    if (__builtin_expect(fabsf(x) < MCX_TRIG_HW_BOUND, 1)) return c ? __builtin_amdgcn_cosf(mcx_trig_phase(x)) : __builtin_amdgcn_sinf(mcx_trig_phase(x));
+    return c ? cosf(x) : sinf(x);
+}
+__device__ __forceinline__ float g_ballot(float x, int c) {          // guard variant: unconditional hardware path, wave-level test for the slow one
+    float r = c ? __builtin_amdgcn_cosf(mcx_trig_phase(x)) : __builtin_amdgcn_sinf(mcx_trig_phase(x));
+    const bool far = !(fabsf(x) < MCX_TRIG_HW_BOUND);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(far) != 0ull, 0)) { if (far) r = c ? cosf(x) : sinf(x); }
+    return r;
+}
+__device__ __forceinline__ float g_none(float x, int c) { return c ? __builtin_amdgcn_cosf(mcx_trig_phase(x)) : __builtin_amdgcn_sinf(mcx_trig_phase(x)); }
+#else
+__device__ float g_expect(float, int); __device__ float g_ballot(float, int); __device__ float g_none(float, int);
+#endif
+
 template <int FORM, int COS>
 __device__ __forceinline__ float eval(float x) {
+    if constexpr (FORM == 4) return g_expect(x, COS);
+    if constexpr (FORM == 5) return g_ballot(x, COS);
+    if constexpr (FORM == 6) return g_none(x, COS);
     if constexpr (FORM == 0) return COS ? cosf(x) : sinf(x);
     else if constexpr (FORM == 1) return COS ? __cosf(x) : __sinf(x);
     else if constexpr (FORM == 2) return COS ? __builtin_amdgcn_cosf(phase(x)) : __builtin_amdgcn_sinf(phase(x));
@@ -152,6 +171,7 @@ int main() {
     }
     printf("nominal cycles per wave per (sin, cos) pair, loop overhead included: ocml %.1f  v_sin %.1f  comp. fract %.1f  mcx_sin/cos %.1f\n", rate<0>(d_out), rate<1>(d_out),
            rate<2>(d_out), rate<3>(d_out));
+    printf("guard variants, same units: unlikely-marked %.1f  wave-level test %.1f  no guard %.1f\n", rate<4>(d_out), rate<5>(d_out), rate<6>(d_out));
     pow_report(d_w, d_out);
     return 0;
 }

@@ -485,7 +485,7 @@ MCX_DEV float mcx_select(float f, float t, bool c) { return c ? t : f; }
 // exact product less n), so the phase lies in [-0.5, 0.5] and is good to 2^-25 revolutions whatever |x| is, and
 // small arguments keep their relative accuracy. Measured over 2^24 points per range (tools/ubench/trig_accuracy.hip,
 // profiles/r03_trig_pow_accuracy.txt): absolute error <= 2.6e-7 for |x| <= 128 and <= 4e-7 up to 1e6, against 7e-8 for
-// ocml and the 4.9e-4 WGSL promises on [-pi, pi]; 77 against 146 cycles per wave for a (sin, cos) pair, the range check
+// ocml and the 4.9e-4 WGSL promises on [-pi, pi]; 61 against 146 cycles per wave for a (sin, cos) pair, the range check
 // included. From 1e6 on (where consecutive floats are 0.06 rad apart and more) the ocml routine runs.
 MCX_DEV float mcx_trig_phase(float x) {
     const float c_hi = 0x1.45f306p-3f, c_lo = 0x1.b9391p-28f;
@@ -493,12 +493,25 @@ MCX_DEV float mcx_trig_phase(float x) {
     return __builtin_fmaf(x, c_lo, __builtin_fmaf(x, c_hi, -n));
 }
 #define MCX_TRIG_HW_BOUND 1.0e6f
-MCX_DEV float mcx_sin(float x) { return fabsf(x) < MCX_TRIG_HW_BOUND ? __builtin_amdgcn_sinf(mcx_trig_phase(x)) : sinf(x); }
-MCX_DEV float mcx_cos(float x) { return fabsf(x) < MCX_TRIG_HW_BOUND ? __builtin_amdgcn_cosf(mcx_trig_phase(x)) : cosf(x); }
+// The range check is a wave-level one: every lane takes the hardware path, and only a wave that holds an argument beyond
+// the bound branches (a scalar branch on the ballot) to patch those lanes with the ocml value -- 61 cycles per (sin, cos)
+// pair against 79 for a per-lane if / else around the two paths and 45 with no check at all.
+#define MCX_RARE_LANES(cond) (__builtin_expect(__builtin_amdgcn_ballot_w64(cond) != 0ull, 0) && (cond))
+MCX_DEV float mcx_sin(float x) {
+    float r = __builtin_amdgcn_sinf(mcx_trig_phase(x));
+    if (MCX_RARE_LANES(!(fabsf(x) < MCX_TRIG_HW_BOUND))) r = sinf(x);
+    return r;
+}
+MCX_DEV float mcx_cos(float x) {
+    float r = __builtin_amdgcn_cosf(mcx_trig_phase(x));
+    if (MCX_RARE_LANES(!(fabsf(x) < MCX_TRIG_HW_BOUND))) r = cosf(x);
+    return r;
+}
 MCX_DEV float mcx_tan(float x) {
-    if (!(fabsf(x) < MCX_TRIG_HW_BOUND)) return tanf(x);
     const float ph = mcx_trig_phase(x);
-    return __builtin_amdgcn_sinf(ph) * __builtin_amdgcn_rcpf(__builtin_amdgcn_cosf(ph));
+    float r = __builtin_amdgcn_sinf(ph) * __builtin_amdgcn_rcpf(__builtin_amdgcn_cosf(ph));
+    if (MCX_RARE_LANES(!(fabsf(x) < MCX_TRIG_HW_BOUND))) r = tanf(x);
+    return r;
 }
 // pow as WGSL defines its accuracy, exp2(y * log2(x)) on v_log_f32 / v_exp_f32 (relative error about
 // 1.2e-7 * (1 + |y * log2 x|); 40 against 600 cycles per wave for ocml powf), with powf's results for a negative
@@ -506,12 +519,12 @@ MCX_DEV float mcx_tan(float x) {
 // and NaNs in either argument take the ocml routine.
 MCX_DEV float mcx_pow(float x, float y) {
     const float ax = fabsf(x);
-    if (!(ax >= 0x1p-126f && ax < __builtin_inff() && fabsf(y) < __builtin_inff())) return powf(x, y);
     float r = __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(ax));
     if (x < 0.0f) {
         const float h = 0.5f * y;
         r = (truncf(y) != y) ? __builtin_nanf("") : ((truncf(h) != h) ? -r : r);
     }
+    if (MCX_RARE_LANES(!(ax >= 0x1p-126f && ax < __builtin_inff() && fabsf(y) < __builtin_inff()))) r = powf(x, y);
     return r;
 }
 MCX_DEV float mcx_degrees(float r) { return r * 57.29577951308232f; }
