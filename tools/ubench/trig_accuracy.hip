@@ -2,6 +2,7 @@
 //   0 ocml sinf / cosf                      (math="precise", and "default" outside the guarded range)
 //   1 v_sin_f32(x * 1/2pi)                  (__sinf / __cosf, math="fast")
 //   2 v_sin_f32 of a compensated x / 2pi    (two-constant product, the phase kept to ~2^-25 revolutions)
+// (and, further down, tan, pow, sinh and cosh of the default mode against their ocml routines)
 // against sin / cos evaluated in f64 on the device, over 2^24 evenly spaced points of [-B, B] for a list of B.
 // Prints the largest absolute error and the time per wave-call of each form.
 //   hipcc --offload-arch=gfx950 -O3 -o tools/ubench/trig_accuracy tools/ubench/trig_accuracy.hip
@@ -13,6 +14,7 @@
 #include "../../wgpu-monte-carlo_amd/csrc/device/mcx_device.hpp"
 #else
 __device__ float mcx_sin(float); __device__ float mcx_cos(float); __device__ float mcx_tan(float); __device__ float mcx_pow(float, float);
+__device__ float mcx_sinh(float); __device__ float mcx_cosh(float);
 #endif
 
 __device__ __forceinline__ float phase(float x) {
@@ -135,6 +137,45 @@ __global__ void __launch_bounds__(256) tan_err_kernel(double* worst, float bound
     if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)worst, (unsigned long long)__double_as_longlong(w));
 }
 
+// sinh / cosh: relative error over [-bound, bound] (sinh: relative to max(|sinh x|, 1e-30))
+template <int FORM, int COSH>
+__global__ void __launch_bounds__(256) hyp_err_kernel(double* worst, float bound, unsigned n) {
+    double w = 0.0;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float x = -bound + 2.0f * bound * ((float)i / (float)(n - 1));
+        double want = COSH ? cosh((double)x) : sinh((double)x);
+        float got = COSH ? (FORM == 0 ? coshf(x) : mcx_cosh(x)) : (FORM == 0 ? sinhf(x) : mcx_sinh(x));
+        double e = fabs((double)got - want) / fmax(fabs(want), 1e-30);
+        if (want > 3.4e38 || want < -3.4e38) e = (fabsf(got) > 3.39e38f && (got > 0) == (want > 0)) ? 0.0 : 1.0;     // overflow: the infinity, or the last finite floats at its edge
+        w = e > w ? e : w;
+    }
+    for (int o = 32; o; o >>= 1) { double v = __shfl_xor(w, o); w = v > w ? v : w; }
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)worst, (unsigned long long)__double_as_longlong(w));
+}
+
+template <int FORM>
+__global__ void __launch_bounds__(256) hyp_rate_kernel(float* out, int iters, float seed) {
+    float a = seed + threadIdx.x * 1e-3f, s = 0.f;
+    for (int i = 0; i < iters; ++i) { s += FORM == 0 ? sinhf(a) + coshf(a) : mcx_sinh(a) + mcx_cosh(a); a += 0.37f; if (a > 30.f) a -= 60.f; }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+void hyp_report(double* d_w, float* d_out) {
+    for (float b : {1e-3f, 0.5f, 4.f, 30.f, 88.f, 95.f}) {
+        double w[4];
+        hipMemset(d_w, 0, 8); hyp_err_kernel<0, 0><<<2048, 256>>>(d_w, b, 1u << 24); hipMemcpy(&w[0], d_w, 8, hipMemcpyDeviceToHost);
+        hipMemset(d_w, 0, 8); hyp_err_kernel<1, 0><<<2048, 256>>>(d_w, b, 1u << 24); hipMemcpy(&w[1], d_w, 8, hipMemcpyDeviceToHost);
+        hipMemset(d_w, 0, 8); hyp_err_kernel<0, 1><<<2048, 256>>>(d_w, b, 1u << 24); hipMemcpy(&w[2], d_w, 8, hipMemcpyDeviceToHost);
+        hipMemset(d_w, 0, 8); hyp_err_kernel<1, 1><<<2048, 256>>>(d_w, b, 1u << 24); hipMemcpy(&w[3], d_w, 8, hipMemcpyDeviceToHost);
+        printf("[-%g, %g] worst relative error: sinh ocml %.3e mcx_sinh %.3e   cosh ocml %.3e mcx_cosh %.3e\n", b, b, w[0], w[1], w[2], w[3]);
+    }
+    float ms[2]; hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hyp_rate_kernel<0><<<2048, 256>>>(d_out, 100, 0.1f);
+    hipEventRecord(a); hyp_rate_kernel<0><<<2048, 256>>>(d_out, 4000, 0.1f); hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms[0], a, b);
+    hipEventRecord(a); hyp_rate_kernel<1><<<2048, 256>>>(d_out, 4000, 0.1f); hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms[1], a, b);
+    printf("nominal cycles per wave per (sinh, cosh) pair: ocml %.1f  mcx %.1f\n", ms[0] * 1e-3 * 2.4e9 / 32000.0, ms[1] * 1e-3 * 2.4e9 / 32000.0);
+}
+
 void pow_report(double* d_w, float* d_out) {
     {
         int* d_bad; hipMalloc(&d_bad, 4); hipMemset(d_bad, 0, 4);
@@ -173,5 +214,6 @@ int main() {
            rate<2>(d_out), rate<3>(d_out));
     printf("guard variants, same units: unlikely-marked %.1f  wave-level test %.1f  no guard %.1f\n", rate<4>(d_out), rate<5>(d_out), rate<6>(d_out));
     pow_report(d_w, d_out);
+    hyp_report(d_w, d_out);
     return 0;
 }

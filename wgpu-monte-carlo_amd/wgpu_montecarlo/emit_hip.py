@@ -51,7 +51,7 @@ _ARITY = {"min": 2, "max": 2, "clamp": 3, "mix": 3, "step": 2, "smoothstep": 3, 
 #              v_rcp_f32: 1-2 ulp, exp degrading like 2|x| ulp); sin / cos / tan use v_sin_f32 / v_cos_f32 behind a
 #              two-constant argument reduction (absolute error <= 4e-7 for |x| < 1e6, ocml beyond: device/mcx_device.hpp
 #              mcx_sin) and pow is exp2(y * log2|x|) with powf's sign and NaN rules (relative error about
-#              1.2e-7 * (1 + |y log2 x|), mcx_pow). All of it is inside the accuracy WGSL itself promises for these
+#              1.2e-7 * (1 + |y log2 x|), mcx_pow); sinh / cosh are (exp(x) -+ exp(-x)) / 2 on v_exp_f32 (mcx_sinh). All of it is inside the accuracy WGSL itself promises for these
 #              operations (division 2.5 ulp, exp 3 + 2|x| ulp, log 3 ulp, sqrt via inverseSqrt 2 ulp, sin / cos 2^-11
 #              absolute on [-pi, pi], pow "as exp2(y * log2 x)"), i.e. inside what the reference's own backends deliver.
 #              Measured: profiles/r03_trig_pow_accuracy.txt.
@@ -61,7 +61,7 @@ _NATIVE_FUNCS = {
     "exp": "__expf({0})", "exp2": "__builtin_amdgcn_exp2f({0})", "log": "__logf({0})",
     "log2": "__builtin_amdgcn_logf({0})", "sqrt": "__builtin_amdgcn_sqrtf({0})",
 }
-_DEFAULT_FUNCS = dict(_NATIVE_FUNCS, sin="mcx_sin({0})", cos="mcx_cos({0})", tan="mcx_tan({0})",
+_DEFAULT_FUNCS = dict(_NATIVE_FUNCS, sin="mcx_sin({0})", cos="mcx_cos({0})", tan="mcx_tan({0})", sinh="mcx_sinh({0})", cosh="mcx_cosh({0})",
                       pow="mcx_pow({0}, {1})", power="mcx_pow({0}, {1})")
 _FAST_FUNCS = dict(_DEFAULT_FUNCS, sin="__sinf({0})", cos="__cosf({0})", tan="__tanf({0})")
 MATH_MODES = ("precise", "default", "fast")

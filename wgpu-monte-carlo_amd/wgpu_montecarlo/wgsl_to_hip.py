@@ -46,7 +46,7 @@ _BUILTINS = {
 # the hardware exp / log / sqrt, the range-reduced hardware sin / cos / tan and exp2(y log2|x|) for pow (device/mcx_device.hpp)
 _MATH_BUILTINS = {
     "precise": {},
-    "default": {"sin": "mcx_sin", "cos": "mcx_cos", "tan": "mcx_tan", "pow": "mcx_pow", "exp": "__expf", "exp2": "__builtin_amdgcn_exp2f",
+    "default": {"sin": "mcx_sin", "cos": "mcx_cos", "tan": "mcx_tan", "sinh": "mcx_sinh", "cosh": "mcx_cosh", "pow": "mcx_pow", "exp": "__expf", "exp2": "__builtin_amdgcn_exp2f",
                 "log": "__logf", "log2": "__builtin_amdgcn_logf", "sqrt": "__builtin_amdgcn_sqrtf"},
 }
 _MATH_BUILTINS["fast"] = dict(_MATH_BUILTINS["default"], sin="__sinf", cos="__cosf", tan="__tanf")
