@@ -135,6 +135,7 @@ def spawn_ranks(args, argv, popen=subprocess.Popen):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(0 if args.single_device else rank),
                    WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MCX_BENCH_CHILD="1",
                    MCX_BENCH_COLD=json.dumps(cold))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between the ranks' processes on this driver
         procs.append(popen([sys.executable, str(ROOT / "bench.py")] + list(argv), env=env,
                            stdout=subprocess.PIPE if rank == 0 else None, text=True))
     # supervise: if any rank fails, stop the others (they would otherwise sit in the rendezvous / a collective)
@@ -713,6 +714,7 @@ def run_rank(args):
     import torch
     import torch.distributed as dist
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before anything initialises the GPU (ranks started by torch.distributed.run)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
