@@ -1,7 +1,11 @@
 """Kernel time and values of the reference benchmark integrand (examples/benchmark.py: x / (exp(sin x) + cos(exp x))), sin x and cos 5x on
 N(0,1) in the three math modes, n = 1e7 and 1e9. Run on the GPU box: python tools/trig_probe.py -> profiles/r03_trig_pow_accuracy.txt."""
-import sys, math, json
-sys.path[:0]=['/root/repo/wgpu-monte-carlo_amd']
+import json
+import math
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "wgpu-monte-carlo_amd"))
 import numpy as np
 from wgpu_montecarlo import Distribution, MonteCarloIntegrator
 f_bench = lambda x: x / (math.exp(math.sin(x)) + math.cos(math.exp(x)))

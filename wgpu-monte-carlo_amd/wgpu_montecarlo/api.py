@@ -268,8 +268,9 @@ class MonteCarloIntegrator:
             MCX_DISTRIBUTED=1 to make None mean "world"); "world": the world group of the initialised
             torch.distributed job; or a torch.distributed process group. Sharding is opt-in because every sharded
             call is a collective: all ranks of the group must make it.
-        math: "default" (hardware exp/log/sqrt/rcp within WGSL's accuracy contract, ocml sin/cos/pow),
-            "fast" (also hardware sin/cos/tan) or "precise" (ocml + IEEE division everywhere).
+        math: "default" (the hardware exp / log / sqrt / rcp, range-reduced hardware sin / cos / tan, pow as exp2(y log2|x|),
+            sinh / cosh on the hardware exp: all within the accuracy WGSL itself promises for these builtins, emit_hip.py),
+            "fast" (sin / cos / tan as the bare instructions, |x| < ~1600) or "precise" (ocml + IEEE division everywhere).
         strict_reference_uniform: reproduce u = float(hash)*2^-32 on the closed interval [0,1]
             (reference behaviour, can produce log(0)); default False guards the end points.
         rng: "pcg_ref" (default) is the reference's counter hash -- bit-exact sample indexing, but a 32-bit
