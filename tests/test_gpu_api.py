@@ -214,7 +214,7 @@ def test_default_trig_and_pow_stay_within_their_stated_error_on_wide_arguments()
               lambda x: 2.0 ** x, lambda x: np.abs(x) ** 0.5, lambda x: x ** (0.0 * x), lambda x: (0.0 * x) ** (x * x)]
     got = {m: MonteCarloIntegrator(math=m).integrate(powers, D().uniform(-4.0, 5.0), n_samples=1_000_000, seed=9).values for m in ("precise", "default")}
     assert np.all(np.isfinite(got["precise"])) and np.allclose(got["default"], got["precise"], rtol=3e-6, atol=1e-7), got
-    hyper = [lambda x: math.sinh(x), lambda x: math.cosh(x), lambda x: math.sinh(0.01 * x) * 100.0, lambda x: math.cosh(0.5 * x) / (1.0 + math.sinh(np.abs(x)))]
+    hyper = [lambda x: math.sinh(x), lambda x: math.cosh(x), lambda x: math.tanh(x) + 10.0 * math.tanh(0.02 * x) + math.tanh(20.0 * x), lambda x: math.sinh(0.01 * x) * 100.0, lambda x: math.cosh(0.5 * x) / (1.0 + math.sinh(np.abs(x)))]
     got = {m: MonteCarloIntegrator(math=m).integrate(hyper, D().uniform(-4.0, 5.0), n_samples=1_000_000, seed=9).values for m in ("precise", "default")}
     assert np.allclose(got["default"], got["precise"], rtol=2e-6, atol=2e-6), got
     r = MonteCarloIntegrator().integrate([lambda x: x ** 0.5], D().normal(0.0, 1.0), n_samples=100_000)
