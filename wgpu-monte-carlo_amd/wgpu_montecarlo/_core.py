@@ -20,7 +20,9 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-from . import runtime, wgsl_to_hip
+from . import emit_hip, runtime, wgsl_to_hip
+
+_SOURCES: dict = {}          # (function strings, math) -> HIP text; bounded, oldest out
 
 _DIST = {"uniform": runtime.DIST_UNIFORM, "normal": runtime.DIST_NORMAL, "exponential": runtime.DIST_EXPONENTIAL,
          "custom": runtime.DIST_CUSTOM}
@@ -88,7 +90,22 @@ class MonteCarloIntegrator:
     def _source(self, functions: Sequence[str]) -> str:
         if len(functions) == 0:
             raise ValueError("At least one function is required")          # src/lib.rs:61-65
-        return "\n\n".join(wgsl_to_hip.translate(text, i, f"user_func_{i}", self._math) for i, text in enumerate(functions))
+        # translated once per distinct list of strings (the reference's Python half sends the same texts call after call: 80-220 us
+        # of tokenising and parsing each time otherwise). The prelude carries McxPowI: `pow(x, 2.0)`, the transpiler's text for
+        # x**2, becomes a product chain in every math mode.
+        key = (tuple(functions), self._math)
+        try:
+            return _SOURCES[key]
+        except (KeyError, TypeError):
+            pass
+        src = "\n\n".join([emit_hip.prelude()] + [wgsl_to_hip.translate(text, i, f"user_func_{i}", self._math) for i, text in enumerate(functions)])
+        try:
+            if len(_SOURCES) >= 256:
+                _SOURCES.pop(next(iter(_SOURCES)))
+            _SOURCES[key] = src
+        except TypeError:                                # an unhashable element: translate() has already raised for non-strings
+            pass
+        return src
 
     def _cdf(self, dist_type: str, x_table, cdf_table):
         if dist_type != "custom":

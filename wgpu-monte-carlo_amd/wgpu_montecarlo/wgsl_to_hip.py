@@ -13,7 +13,7 @@ and is renamed `user_func_<i>`; helper functions that follow keep their names be
 from __future__ import annotations
 
 import re
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 from .frontend import TranspilerError
 
@@ -55,6 +55,18 @@ _BINARY_LEVELS: List[Tuple[str, ...]] = [
     ("||",), ("&&",), ("|",), ("^",), ("&",), ("==", "!="), ("<", ">", "<=", ">="), ("<<", ">>"),
     ("+", "-"), ("*", "/", "%"),
 ]
+
+
+_WHOLE = re.compile(r"^\(*(-?)\(*(\d+)(?:\.0*)?f?\)*$")
+
+
+def _whole_exponent(text: str) -> Optional[int]:
+    """The value of a translated literal such as `2.0f`, `(-3.0f)` or `4` if it is a whole number of at most 64 in magnitude."""
+    m = _WHOLE.match(text.replace(" ", ""))
+    if not m or text.count("(") != text.count(")"):
+        return None
+    n = int(m.group(2))
+    return None if n > 64 else (-n if m.group(1) else n)
 
 
 def _tokenize(text: str) -> List[Tuple[str, str]]:
@@ -190,6 +202,12 @@ class _Parser:
                 if len(args) != 3:
                     raise TranspilerError("WGSL function string: select() takes three arguments")
                 return f"(({args[2]}) ? ({args[1]}) : ({args[0]}))"
+            if value == "pow" and len(args) == 2 and _whole_exponent(args[1]) is not None:
+                # a literal whole exponent (what the reference's transpiler writes for x**k: `pow(x, 2.0)`) is a product
+                # chain, as on the Python path (emit_hip.py); the caller supplies McxPowI (emit_hip.prelude())
+                n = _whole_exponent(args[1])
+                chain = f"McxPowI<{abs(n)}>::of({args[0]})"
+                return chain if n >= 0 else f"(1.0f / {chain})"
             if value in self.builtins:
                 return f"{self.builtins[value]}({', '.join(args)})"
             if value in _TABLE_CALLS and value not in self.local_functions:
