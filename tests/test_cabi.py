@@ -276,3 +276,29 @@ def test_module_key_names_the_cached_code_object():
     rt.precompile(src, desc)
     assert (Path(rt.cache_dir()) / f"{key}.hsaco").exists()
     assert rt.module_key(src, rt.make_desc(rt.KIND_INTEGRATE, 1, rt.DIST_NORMAL)) != key
+
+
+def test_core_binding_recognises_the_references_importance_sampling_wrappers():
+    """`_core` (math != "precise") compiles the K wrappers the reference's Python half generates as K integrands + one weight
+    (wgpu_montecarlo/_core.py: _split_weighted). The recorded payloads are the reference's own text; anything else stays literal."""
+    import json
+    from pathlib import Path
+
+    from wgpu_montecarlo import _core
+
+    meta = json.loads((Path(__file__).resolve().parent / "golden" / "boundary_payloads.json").read_text())
+    wgsl = lambda i: meta[i]["args"][0]["wgsl"]
+    assert _core._split_weighted(wgsl(1)) is None                                   # plain integrands (C2)
+    f, p, q = _core._split_weighted(wgsl(2))                                        # C3: target from its table, analytic proposal
+    assert len(f) == 4 and p is None and q is not None and "_is_pdf_q(" in q and "_is_f_orig_3" in f[3] and "pow(x, 4.0)" in f[3]
+    assert _core._is_normal_pdf_text(q, 2.0, 3.0) and not _core._is_normal_pdf_text(q, 2.0, 3.5) and not _core._is_normal_pdf_text(None, 2.0, 3.0)
+    f, p, q = _core._split_weighted(wgsl(5))                                        # analytic target and proposal
+    assert len(f) == 1 and "_is_pdf_p(" in p and _core._is_normal_pdf_text(p, 0.0, 1.0) and _core._is_normal_pdf_text(q, 0.5, 1.5)
+    broken = list(wgsl(2))
+    broken[2] = broken[2].replace("sigma: f32 = 3.0", "sigma: f32 = 3.5")           # wrappers around different proposals: not one weight
+    assert _core._split_weighted(broken) is None
+    assert _core._split_weighted([wgsl(2)[0].replace("f_val * p / q", "f_val * p * q")]) is None
+    assert _core._split_weighted([wgsl(2)[0], "fn g(x: f32) -> f32 { return x; }"]) is None
+    helper = wgsl(2)[0] + "\nfn my_helper(y: f32) -> f32 { return y * 2.0; }\n"       # a user string with a helper after its entry
+    f, _, _ = _core._split_weighted([helper])
+    assert "my_helper" in f[0]

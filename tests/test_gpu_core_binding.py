@@ -21,11 +21,13 @@ def _wgsl(fn, name):
     return re.sub(r"fn\s+\w+\s*\(", f"fn {name}(", transpile_function(fn), count=1)
 
 
-@pytest.fixture(scope="module")
-def core():
+@pytest.fixture(scope="module", params=["precise", "default"])
+def core(request):
+    """Both ways the binding compiles what it is handed (wgpu_montecarlo/_core.py): literally, and as the plan this package's
+    API builds for the same call. Every test below holds both to the same bounds."""
     from wgpu_montecarlo import _core
 
-    return _core.MonteCarloIntegrator()
+    return _core.MonteCarloIntegrator(math=request.param)
 
 
 def test_integrate_takes_the_transpilers_wgsl(core, integrator):
@@ -216,20 +218,21 @@ def test_error_mapping(core):
         core.integrate(["fn f(x: f32) -> f32 { return nope(x); }"], "normal", {}, 1000, 1)
 
 
-def test_the_binding_takes_a_math_mode(core, monkeypatch):
-    """`math` (and MCX_CORE_MATH for callers that cannot pass it) selects the routines behind the WGSL builtins of the
-    function strings; the default stays ocml. Uniform sampling: the same samples in every mode."""
+def test_the_binding_takes_a_math_mode(monkeypatch):
+    """`math` (and MCX_CORE_MATH for callers that cannot pass it) selects how the binding compiles the strings, here the
+    routines behind their WGSL builtins; "precise" is the literal, ocml one. Uniform sampling: the same samples in every mode."""
     from wgpu_montecarlo import _core
 
     texts = ["fn f(x: f32) -> f32 { return x / (exp(sin(x)) + 2.0 + cos(exp(x))); }",
              "fn g(x: f32) -> f32 { return pow(abs(x), 1.5) + tan(0.3 * x) + sqrt(abs(x)) * log(1.0 + x * x); }"]
     args = (texts, "uniform", {"min": -3.0, "max": 3.0}, 1_000_000, 11)
-    precise = core.integrate(*args)
-    assert np.array_equal(precise, _core.MonteCarloIntegrator(math="precise").integrate(*args))
-    default = _core.MonteCarloIntegrator(math="default").integrate(*args)
+    monkeypatch.delenv("MCX_CORE_MATH", raising=False)
+    default = _core.MonteCarloIntegrator().integrate(*args)
+    assert np.array_equal(default, _core.MonteCarloIntegrator(math="default").integrate(*args))
+    precise = _core.MonteCarloIntegrator(math="precise").integrate(*args)
     assert np.allclose(default, precise, rtol=0, atol=2e-6) and not np.array_equal(default, precise)
-    monkeypatch.setenv("MCX_CORE_MATH", "default")
-    assert np.array_equal(_core.MonteCarloIntegrator().integrate(*args), default)
+    monkeypatch.setenv("MCX_CORE_MATH", "precise")
+    assert np.array_equal(_core.MonteCarloIntegrator().integrate(*args), precise)
     assert np.allclose(_core.MonteCarloIntegrator(math="fast").integrate(*args), precise, rtol=0, atol=5e-6)
     with pytest.raises(ValueError):
         _core.MonteCarloIntegrator(math="quick")

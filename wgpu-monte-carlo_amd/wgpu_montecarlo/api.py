@@ -125,6 +125,28 @@ def functions_to_hip(functions: Sequence[FunctionLike], math="default") -> str:
     return "\n\n".join(parts)
 
 
+def build_module(engine, user_src: str, desc, *tables: Optional[runtime.Table], extra_bytes: int = 0):
+    """Build (or fetch) the module for `desc`, then hold the plan-time LDS decisions against the code object's REAL
+    static LDS (the launch checks it: csrc/mcx_runtime.cpp integrate_impl / mcmc_impl). _fit_tables decided with an
+    upper bound; should the real figure ever be larger, a default-on optimisation (staged tables, cell_noclamp,
+    cell_addr16) must fall back to the slower form, not turn a valid call into MCX_E_INVALID. Shared with the
+    `_core` binding (_core.py)."""
+    mod = engine.module(user_src, desc)
+    if not desc.tables_lds:
+        return mod
+    need = sum(tb.lds_bytes for tb in tables if tb is not None) + (extra_bytes if desc.cell_noclamp else 0)
+    if desc.cdf_direct:
+        need += (mod.block // 64) * 128 * 4             # the per-wave queues of the bucket-direct sampler
+    total = need + mod.static_lds
+    if need and total > runtime.LDS_PER_CU:
+        desc.tables_lds, desc.cdf_direct, desc.cell_noclamp, desc.cell_addr16 = 0, 0, 0, 0
+        return engine.module(user_src, desc)
+    if desc.cell_addr16 and total > 65536:
+        desc.cell_addr16 = 0
+        return engine.module(user_src, desc)
+    return mod
+
+
 _MOMENT_FAMILY_MIN_K = 8     # below this the per-sample multiply chain is as cheap (K = 4: 10 ops per pair against 12)
 
 
@@ -417,24 +439,7 @@ class MonteCarloIntegrator:
         return desc
 
     def _build_module(self, user_src: str, desc, *tables: Optional[runtime.Table], extra_bytes: int = 0):
-        """Build (or fetch) the module for `desc`, then hold the plan-time LDS decisions against the code object's REAL
-        static LDS (the launch checks it: csrc/mcx_runtime.cpp integrate_impl / mcmc_impl). _fit_tables decided with an
-        upper bound; should the real figure ever be larger, a default-on optimisation (staged tables, cell_noclamp,
-        cell_addr16) must fall back to the slower form, not turn a valid call into MCX_E_INVALID."""
-        mod = self._engine.module(user_src, desc)
-        if not desc.tables_lds:
-            return mod
-        need = sum(tb.lds_bytes for tb in tables if tb is not None) + (extra_bytes if desc.cell_noclamp else 0)
-        if desc.cdf_direct:
-            need += (mod.block // 64) * 128 * 4             # the per-wave queues of the bucket-direct sampler
-        total = need + mod.static_lds
-        if need and total > runtime.LDS_PER_CU:
-            desc.tables_lds, desc.cdf_direct, desc.cell_noclamp, desc.cell_addr16 = 0, 0, 0, 0
-            return self._engine.module(user_src, desc)
-        if desc.cell_addr16 and total > 65536:
-            desc.cell_addr16 = 0
-            return self._engine.module(user_src, desc)
-        return mod
+        return build_module(self._engine, user_src, desc, *tables, extra_bytes=extra_bytes)
 
     def _cell_pads(self, cell_tables: bool, code: int, p1: float, p2: float, cdf, *tables) -> Optional[int]:
         """desc.cell_noclamp: can every cell table of the call be padded over the sampler's range (then the lookup needs
