@@ -302,3 +302,15 @@ def test_core_binding_recognises_the_references_importance_sampling_wrappers():
     helper = wgsl(2)[0] + "\nfn my_helper(y: f32) -> f32 { return y * 2.0; }\n"       # a user string with a helper after its entry
     f, _, _ = _core._split_weighted([helper])
     assert "my_helper" in f[0]
+
+
+def test_core_binding_recognises_the_fused_moments_workload():
+    from wgpu_montecarlo import _core, transpile_function
+
+    second = transpile_function(lambda x: x**2)                       # the transpiler's text for x**2 ...
+    assert "return pow(x, 2.0);" in second
+    texts = [transpile_function(lambda x: x)] + [second.replace("pow(x, 2.0)", f"pow(x, {k}.0)") for k in range(2, 33)]   # ... and for x**k
+    assert "return x;" in texts[0] and "pow(x, 32.0)" in texts[31]
+    assert _core._moment_family(texts) and _core._moment_family(texts[:8]) and not _core._moment_family(texts[:7])
+    assert not _core._moment_family(texts[1:]) and not _core._moment_family(texts[:9] + [texts[11]] + texts[10:])
+    assert not _core._moment_family(texts[:8] + ["fn f(x: f32) -> f32 { return pow(x, 9.0) + 0.0; }"])

@@ -82,6 +82,23 @@ def _split_weighted(functions):
     return f_texts, next(iter(p_seen)), next(iter(q_seen))
 
 
+_MOMENT_X = re.compile(r"^\s*fn\s+\w+\s*\(\s*x\s*:\s*f32\s*\)\s*->\s*f32\s*\{\s*return\s+x\s*;\s*\}\s*$")
+_MOMENT_POW = re.compile(r"^\s*fn\s+\w+\s*\(\s*x\s*:\s*f32\s*\)\s*->\s*f32\s*\{\s*return\s+pow\s*\(\s*x\s*,\s*(\d+)(?:\.0*)?\s*\)\s*;\s*\}\s*$")
+
+
+def _moment_family(functions) -> bool:
+    """Are the K >= 8 strings exactly the transpiler's text for x, x**2, .., x**K (`return x;`, `return pow(x, k.0);`)? Then
+    the kernel accumulates the power sums of two / four samples at a time (desc.moment_family), as api._moment_family
+    decides from the IR for the same workload (BASELINE configs[4])."""
+    if len(functions) < 8 or not all(isinstance(t, str) for t in functions) or not _MOMENT_X.match(functions[0]):
+        return False
+    for i, text in enumerate(functions[1:], start=2):
+        m = _MOMENT_POW.match(text)
+        if not m or int(m.group(1)) != i:
+            return False
+    return True
+
+
 def _is_normal_pdf_text(text: Optional[str], mean: float, std: float) -> bool:
     """Is `text` the closure Distribution.normal(mean, std) hands the transpiler (python/wgpu_montecarlo/__init__.py:343-347:
     exp(-0.5 z z) / (sigma sqrt_2pi), z = (x - mean) / sigma), for exactly the parameters the call samples with? Then 1/q is a
@@ -283,7 +300,8 @@ class MonteCarloIntegrator:
             mod = self._engine.module(src, desc)
         else:
             desc = runtime.make_desc(runtime.KIND_INTEGRATE, k, code, guard_endpoints=True, user_tables=mask,
-                                     unit_params=_unit_params(code, p1, p2), cdf_direct=self._cdf_direct(cdf, k))
+                                     unit_params=_unit_params(code, p1, p2), cdf_direct=self._cdf_direct(cdf, k),
+                                     moment_family=mask == 0 and k <= 32 and _moment_family(functions))
             # user functions may look the tables up at any argument, not only at the draw: the index clamp stays (pads=False)
             mod = self._fitted_module(src, desc, code, p1, p2, cdf, p_tab, q_tab, pads=False)
         sums, n_eff = self._engine.integrate(mod, int(n_samples), int(seed), p1, p2, target_threads, cdf=cdf, **tables)
