@@ -47,7 +47,8 @@ int main(int argc, char** argv) {
     LOAD(mcx_module_build) LOAD(mcx_module_release) LOAD(mcx_integrate) LOAD(mcx_engine_last_kernel_ms)
     LOAD(mcx_hip_runtime) LOAD(mcx_comm_create) LOAD(mcx_comm_destroy) LOAD(mcx_comm_size) LOAD(mcx_integrate_comm)
     LOAD(mcx_rccl_library) LOAD(mcx_lds_table_budget) LOAD(mcx_module_static_lds) LOAD(mcx_engine_last_launch_count)
-    LOAD(mcx_abi_version) LOAD(mcx_result_rows)
+    LOAD(mcx_abi_version) LOAD(mcx_result_rows) LOAD(mcx_table_create) LOAD(mcx_table_release) LOAD(mcx_module_desc_fit)
+    LOAD(mcx_module_build_fitted) LOAD(mcx_module_block)
 
     printf("OK version %s\n", p_mcx_version());
     mcx_dispatch d;
@@ -118,6 +119,41 @@ int main(int argc, char** argv) {
         p_mcx_comm_destroy(c);
         printf("OK rccl communicator (1 rank) on %s: same sums\n", p_mcx_rccl_library());
     }
+#ifndef MCX_CLIENT_OLD_LAYOUT
+    {   /* importance sampling with a target table, planned by libmcx itself: E_p[x], E_p[x^2] for p = N(0,1) tabulated on a
+         * 512-point grid, draws from N(0.5, 1.5). mcx_module_desc_fit sets the fields that are guarantees about the table. */
+        enum { N = 512 };
+        static float xs[N], ps[N];
+        for (int i = 0; i < N; ++i) {
+            xs[i] = (float)(-7.0 + 14.0 * i / (N - 1));
+            ps[i] = (float)(exp(-0.5 * (double)xs[i] * (double)xs[i]) / 2.5066282746310002);
+        }
+        mcx_table* t = NULL;
+        if (p_mcx_table_create(e, MCX_TABLE_PDF, xs, ps, N, &t)) { fprintf(stderr, "table: %s\n", p_mcx_last_error()); return 1; }
+        mcx_module_desc wd;
+        mcx_module_desc_init(&wd);
+        wd.kind = MCX_KIND_INTEGRATE; wd.k = 2; wd.dist_type = MCX_DIST_NORMAL; wd.weight = 1; wd.p_table = 1; wd.q_sampler = 1;
+        uint32_t pad_bytes = 0u;
+        if (p_mcx_module_desc_fit(&wd, NULL, t, NULL, 0.5f, 1.5f, &pad_bytes)) { fprintf(stderr, "fit: %s\n", p_mcx_last_error()); return 1; }
+        if (!wd.cell_tables || !wd.cell_noclamp || !wd.tables_lds || wd.unit_params || wd.block != 512 || pad_bytes == 0u) {
+            fprintf(stderr, "fit: cells %d noclamp %d lds %d unit %d block %d pads %u\n", wd.cell_tables, wd.cell_noclamp, wd.tables_lds,
+                    wd.unit_params, wd.block, pad_bytes);
+            return 1;
+        }
+        mcx_module* wm = NULL;
+        if (p_mcx_module_build_fitted(e, USER_SRC, &wd, NULL, t, NULL, pad_bytes, &wm)) { fprintf(stderr, "build_fitted: %s\n", p_mcx_last_error()); return 1; }
+        mcx_integrate_params wp;
+        mcx_integrate_params_init(&wp);
+        wp.n_samples = 50000000ull; wp.seed = 7u; wp.param1 = 0.5f; wp.param2 = 1.5f; wp.target_pdf = t;
+        double ws[2]; uint64_t wn = 0;
+        if (p_mcx_integrate(e, wm, &wp, ws, &wn)) { fprintf(stderr, "weighted integrate: %s\n", p_mcx_last_error()); return 1; }
+        printf("OK fitted importance sampling: cells %d, %u pad bytes, block %u, E_p[x]=%.6f E_p[x^2]=%.6f kernel_ms=%.3f\n", wd.cell_tables,
+               pad_bytes, p_mcx_module_block(wm), ws[0] / (double)wn, ws[1] / (double)wn, p_mcx_engine_last_kernel_ms(e));
+        if (fabs(ws[0] / (double)wn) > 1.5e-3 || fabs(ws[1] / (double)wn - 1.0) > 3e-3) return 1;
+        p_mcx_module_release(wm);
+        p_mcx_table_release(t);
+    }
+#endif
     desc.k = 0;                                                     /* src/lib.rs:61-65 */
     mcx_module* bad = NULL;
     if (p_mcx_module_build(e, USER_SRC, DESC_PTR(&desc), &bad) != MCX_E_INVALID || !strstr(p_mcx_last_error(), "At least one function")) return 1;

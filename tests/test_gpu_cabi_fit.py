@@ -1,0 +1,83 @@
+"""include/mcx.h: mcx_module_desc_fit / mcx_module_build_fitted -- libmcx's own performance planning of a call, for callers of
+the C ABI (which field of mcx_module_desc to set for which tables). The Python host layer makes the same decisions for its
+own calls (wgpu_montecarlo/api.py); here the two are held to the same desc, byte for byte, on the BASELINE workloads and on
+tables that take the other branches (no cell form, too large for LDS, user tables, random-walk proposals)."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+
+
+def _refit(plan_desc, rt, cdf, t0, t1, p1, p2):
+    """A copy of the plan's desc with every planned field cleared, then fitted by libmcx."""
+    d = rt.ModuleDesc.from_buffer_copy(bytes(plan_desc))
+    d.cell_tables = d.cell_noclamp = d.cell_addr16 = d.cdf_direct = d.unit_params = 0
+    d.tables_lds = 1
+    if plan_desc.block == 512:
+        d.block = 0                      # the planner's own choice; an explicit workgroup size (MCMC shards) stays
+    rt.module_desc_fit(d, cdf, t0, t1, p1, p2)
+    return d
+
+
+def _fields(d):
+    return {name: getattr(d, name) for name, _ in d._fields_}
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+def test_libmcx_fits_the_baseline_configs_like_the_python_planner(integrator, name):
+    import baseline_configs as bc
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo import runtime as rt
+
+    wl = bc.get(name, Distribution)
+    plan = wl.prepare(integrator)._plan
+    tb = plan.tables
+    pair = (tb.get("target_logpdf"), tb.get("proposal_logpdf")) if plan.kind == "mcmc" else (tb.get("target_pdf"), tb.get("proposal_pdf"))
+    got = _refit(plan.desc, rt, tb.get("cdf"), pair[0], pair[1], plan.p1, plan.p2)
+    assert _fields(got) == _fields(plan.desc)
+    if name == "c3":
+        assert got.cell_tables and got.cell_noclamp and got.block == 512 and got.tables_lds
+    if name == "c4":
+        assert got.cell_tables and got.cell_addr16
+    if name == "c5":
+        assert got.cdf_direct and got.tables_lds and not got.cell_tables
+
+
+def test_the_other_branches(integrator):
+    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo import runtime as rt
+
+    eng = integrator._engine
+    xs = np.linspace(-4, 4, 400)
+    grid = eng.cached_table(rt.TABLE_PDF, xs.astype(np.float32), np.exp(-0.5 * xs * xs).astype(np.float32))
+    ragged_x = np.sort(np.random.default_rng(1).uniform(-4, 4, 300)).astype(np.float32)
+    ragged = eng.cached_table(rt.TABLE_PDF, ragged_x, np.exp(-0.5 * ragged_x * ragged_x).astype(np.float32))
+    base = lambda **kw: rt.make_desc(rt.KIND_INTEGRATE, 2, rt.DIST_NORMAL, weight=True, p_table=True, **kw)
+    d = base()
+    pad = rt.module_desc_fit(d, None, grid, None, 0.0, 1.0)
+    assert d.cell_tables and d.cell_noclamp and pad > 0 and d.unit_params and d.block == 512
+    d = base()
+    assert rt.module_desc_fit(d, None, ragged, None, 0.5, 1.0) == 0 and not d.cell_tables and not d.cell_noclamp and not d.unit_params
+    d = base(precise_sampler=True)
+    rt.module_desc_fit(d, None, grid, None, 0.0, 1.0)
+    assert not d.cell_tables                                                    # the literal search + blend stays
+    d = rt.make_desc(rt.KIND_INTEGRATE, 2, rt.DIST_NORMAL, user_tables=1)
+    assert rt.module_desc_fit(d, None, grid, None, 0.0, 1.0) == 0 and d.cell_tables and not d.cell_noclamp      # lookups at any argument: the clamp stays
+    d = rt.make_desc(rt.KIND_MCMC, 2, rt.DIST_NORMAL, walk=rt.WALK_RANDOM_SYMMETRIC)
+    logs = eng.cached_table(rt.TABLE_LOGPDF, xs.astype(np.float32), (-0.5 * xs * xs).astype(np.float32))
+    assert rt.module_desc_fit(d, None, logs, None, 0.0, 0.5) == 0 and d.cell_tables and not d.cell_noclamp and d.cell_addr16
+    big_x = np.linspace(-8, 8, 30000)
+    big = eng.cached_table(rt.TABLE_PDF, big_x.astype(np.float32), np.exp(-0.5 * big_x * big_x).astype(np.float32))
+    d = base()
+    rt.module_desc_fit(d, None, big, None, 0.0, 1.0)
+    assert not d.tables_lds and not d.cell_noclamp                               # 240 KB of cells: read from HBM / L2
+    # the fitted module runs, and gives what the Python API gives for the same call
+    target = Distribution.from_pdf_table(xs, np.exp(-0.5 * xs * xs) / np.sqrt(2 * np.pi))
+    fns = [lambda x: x, lambda x: x * x]
+    want = integrator.integrate_importance_sampling(fns, target, Distribution.normal(0.5, 1.5), n_samples=1_000_000, seed=5)
+    assert abs(want.values[1] - 1.0) < 0.02

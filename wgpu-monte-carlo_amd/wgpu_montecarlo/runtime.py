@@ -94,6 +94,7 @@ EXPORTED_SYMBOLS = [
     "mcx_comm_create", "mcx_comm_destroy", "mcx_comm_size", "mcx_integrate_comm", "mcx_mcmc_comm",
     "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct", "mcx_mcmc_block_hint", "mcx_cell_pads", "mcx_cell_pads_host", "mcx_default_launch_blocks", "mcx_engine_set_mcmc_segments",
     "mcx_abi_version", "mcx_module_key", "mcx_table_analyse", "mcx_table_facts_of", "mcx_engine_last_call", "mcx_module_block",
+    "mcx_module_desc_fit", "mcx_module_build_fitted",
 ]
 
 _lib = None
@@ -167,6 +168,8 @@ def load():
         L.mcx_engine_set_mcmc_segments.argtypes = [vp, u32]
         L.mcx_module_build.argtypes = [vp, C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(vp)]
         L.mcx_module_precompile.argtypes = [C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(C.c_int)]
+        L.mcx_module_desc_fit.argtypes = [C.POINTER(ModuleDesc), vp, vp, vp, C.c_float, C.c_float, C.POINTER(u32)]
+        L.mcx_module_build_fitted.argtypes = [vp, C.c_char_p, C.POINTER(ModuleDesc), vp, vp, vp, u32, C.POINTER(vp)]
         L.mcx_result_rows.argtypes = [C.POINTER(ModuleDesc)]
         L.mcx_module_source.argtypes = [C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(vp)]
         L.mcx_free.argtypes = [vp]
@@ -292,6 +295,16 @@ def make_desc(kind: int, k: int, dist_type: int, weight: bool = False, p_table: 
                       int(precise_sampler), int(block), int(tables_lds), int(rng), int(unit_params), int(second_moments),
                       int(walk), int(cell_tables), int(q_sampler), int(moment_family), int(user_tables), int(logpdf_analytic),
                       int(cdf_direct), int(cell_noclamp), int(cell_addr16))
+
+
+def module_desc_fit(desc: ModuleDesc, cdf: Optional["Table"], t0: Optional["Table"], t1: Optional["Table"], p1: float, p2: float) -> int:
+    """libmcx's own performance planning of one call (include/mcx.h: mcx_module_desc_fit): fills cell_tables, cell_noclamp,
+    cell_addr16, tables_lds, cdf_direct, unit_params and block of `desc` in place; returns the LDS bytes of the sentinel pads.
+    What api.py decides for its own calls in Python -- tests/test_gpu_cabi_fit.py holds the two to the same desc."""
+    pad = C.c_uint32(0)
+    h = lambda t: t._h if t is not None else None
+    check(load().mcx_module_desc_fit(C.byref(desc), h(cdf), h(t0), h(t1), float(p1), float(p2), C.byref(pad)))
+    return int(pad.value)
 
 
 def cell_pads(table: "Table", dist_type: int, p1: float, p2: float, cdf: Optional["Table"] = None, guard: bool = True):
