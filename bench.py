@@ -22,7 +22,8 @@ command times ALL of them: c2 is the headline (`value`), c3 / c4 / c5 run throug
 and are reported under `configs` in the same JSON line (--legs), each with its own kernel time, roofline, accuracy on
 both streams and a short CPU-baseline slice. At N > 1 the line also carries `self_check`: an RCCL all-reduce of ones
 (= N) and, per config, the all-reduced shard sums against the whole grid run on rank 0 (`sharded_equals_single`).
-At N = 1 it ends with `reference_protocol`: the reference's own benchmark (examples/benchmark.py: wall clock around blocking
+At N = 1 it also carries `core_binding` (the reference's own `_core` payloads for configs[1..3] replayed through this package's `_core`
+binding) and `reference_protocol`: the reference's own benchmark (examples/benchmark.py: wall clock around blocking
 integrate() calls of x / (exp(sin x) + cos(exp x)) on N(0,1)) at n = 1e3 / 1e5 / 1e7 / 1e9.
 """
 import argparse
@@ -696,6 +697,26 @@ def reference_protocol(ctx):
     return out
 
 
+def core_binding_leg(ctx):
+    """The drop-in boundary itself, N = 1: the payloads the reference's own Python half hands to its native module for BASELINE
+    configs[1..3] (tests/golden/boundary_payloads.*: its transpiler's WGSL, its importance-sampling wrapper text, parameter dicts,
+    float32 tables -- recorded data, replayed verbatim at full size) through this package's `_core` binding (wgpu_montecarlo/_core.py,
+    the reference's `_core.MonteCarloIntegrator` interface over libmcx), blocking calls, best of 3."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import core_payload_bench as cpb
+    from wgpu_montecarlo import _core
+
+    calls = cpb.golden_calls()
+    core = _core.MonteCarloIntegrator(device=ctx.local_rank)
+    out = {"binding": "wgpu_montecarlo._core.MonteCarloIntegrator (WGSL text in, float32[K] out)", "math": core._math, "calls": {}}
+    for name, index in (("c2", 1), ("c3", 2), ("c4", 3)):
+        method, a = calls[index]
+        ms, got = cpb.best(lambda: getattr(core, method)(*a))
+        units = (a[3] if method != "integrate_mcmc" else (a[5] + a[7]) * a[6])
+        out["calls"][name] = {"method": method, "k": len(a[0]), "call_ms": ms, "units_per_s": units / (ms * 1e-3), "values": [float(v) for v in got[:4]]}
+    return out
+
+
 def leg_names(args):
     """BASELINE configs timed next to the headline in the same line (the driver only ever runs the default command)."""
     if args.legs == "none":
@@ -764,6 +785,12 @@ def run_rank(args):
             protocol = reference_protocol(ctx)
         except Exception as exc:                         # noqa: BLE001
             protocol = {"error": f"{type(exc).__name__}: {exc}"[:600]}
+    binding = None
+    if world == 1 and legs and not under_profiler():
+        try:
+            binding = core_binding_leg(ctx)
+        except Exception as exc:                         # noqa: BLE001
+            binding = {"error": f"{type(exc).__name__}: {exc}"[:600]}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -780,6 +807,7 @@ def run_rank(args):
             "cold": cold,
             "configs": legs,
             "reference_protocol": protocol,
+            "core_binding": binding,
             "self_check": None if world == 1 else {
                 "rccl_sum_of_ones": rccl_sum_of_ones,
                 "rccl_sum_of_ones_ok": rccl_sum_of_ones == float(world),
