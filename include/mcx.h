@@ -281,21 +281,6 @@ uint32_t mcx_module_static_lds(const mcx_module* m);
  * scratch its kernel declares. A call whose tables (sum of mcx_table_lds_bytes) exceed it must build the module with
  * tables_lds = 0; launches check the exact figure. 0 for an invalid desc. */
 uint32_t mcx_lds_table_budget(const mcx_module_desc* desc);
-/* Performance planning of one call -- what wgpu_montecarlo/api.py decides for its own calls, for callers of this ABI. Given the
- * tables the call will bind (cdf: the custom sampling / proposal table or NULL; t0, t1: its PDF tables -- target, proposal -- for
- * an integrate module, its log-PDF tables for an MCMC module, NULL where none) and the sampler's parameters, fills the
- * fields of `d` that are guarantees about them: cell_tables (every table a strict grid), cell_noclamp (+ the LDS bytes of the
- * sentinel cells in *pad_bytes), cell_addr16, tables_lds (do they fit next to the kernel's scratch), cdf_direct, unit_params and,
- * when block is 0 and small tables favour it, block = 512. Set everything else (kind, k, dist_type, weight, p_table, q_table,
- * precise_sampler, rng, second_moments, walk, q_sampler, moment_family, user_tables, logpdf_analytic) before the call. The tuning
- * switches of the host layer apply (MCX_NO_NOCLAMP, MCX_NO_ADDR16, MCX_NO_DIRECT, MCX_DIRECT_MAX_ROWS, MCX_BLOCK). */
-int  mcx_module_desc_fit(mcx_module_desc* d, const mcx_table* cdf, const mcx_table* t0, const mcx_table* t1, float param1, float param2,
-                         uint32_t* pad_bytes);
-/* mcx_module_build of a fitted desc, then the plan-time LDS decisions held against the code object's real static LDS: should the
- * staged tables (or cell_addr16's 64 KiB) not fit after all, the flags that need them are cleared in `d` and the module is rebuilt
- * -- a default-on optimisation falls back, it does not fail the launch. */
-int  mcx_module_build_fitted(mcx_engine* e, const char* user_src, mcx_module_desc* d, const mcx_table* cdf, const mcx_table* t0,
-                             const mcx_table* t1, uint32_t pad_bytes, mcx_module** out);
 /* Where code objects are cached (default: <dir of libmcx.so>/jit_cache, override MCX_CACHE_DIR). The in-memory copy
  * is an LRU of MCX_CODE_CACHE_ENTRIES (default 256) code objects. */
 const char* mcx_cache_dir(void);
@@ -351,6 +336,26 @@ typedef struct mcx_table_facts {
 } mcx_table_facts;
 int  mcx_table_analyse(int kind, const float* keys, const float* values, uint32_t n, mcx_table_facts* out);
 int  mcx_table_facts_of(const mcx_table* t, mcx_table_facts* out);       /* the same of a resident table */
+
+/* Performance planning of one call (the host layer of this repo calls it for its own plans). Given the
+ * tables the call will bind (cdf: the custom sampling / proposal table or NULL; t0, t1: its PDF tables -- target, proposal -- for
+ * an integrate module, its log-PDF tables for an MCMC module, NULL where none) and the sampler's parameters, fills the
+ * fields of `d` that are guarantees about them: cell_tables (every table a strict grid), cell_noclamp (+ the LDS bytes of the
+ * sentinel cells in *pad_bytes), cell_addr16, tables_lds (do they fit next to the kernel's scratch), cdf_direct, unit_params and,
+ * when block is 0 and small tables favour it, block = 512. Set everything else (kind, k, dist_type, weight, p_table, q_table,
+ * precise_sampler, rng, second_moments, walk, q_sampler, moment_family, user_tables, logpdf_analytic) before the call. The tuning
+ * switches of the host layer apply (MCX_NO_NOCLAMP, MCX_NO_ADDR16, MCX_NO_DIRECT, MCX_DIRECT_MAX_ROWS, MCX_BLOCK). */
+int  mcx_module_desc_fit(mcx_module_desc* d, const mcx_table* cdf, const mcx_table* t0, const mcx_table* t1, float param1, float param2,
+                         uint32_t* pad_bytes);
+/* The same without a device: the tables as mcx_table_analyse describes them, plus the keys (x column) of t0 / t1 for the pads.
+ * What a GPU-less build step uses to compile exactly the modules a call on the GPU will build. */
+int  mcx_module_desc_fit_host(mcx_module_desc* d, const mcx_table_facts* cdf, const mcx_table_facts* t0, const float* keys0,
+                              const mcx_table_facts* t1, const float* keys1, float param1, float param2, uint32_t* pad_bytes);
+/* mcx_module_build of a fitted desc, then the plan-time LDS decisions held against the code object's real static LDS: should the
+ * staged tables (or cell_addr16's 64 KiB) not fit after all, the flags that need them are cleared in `d` and the module is rebuilt
+ * -- a default-on optimisation falls back, it does not fail the launch. */
+int  mcx_module_build_fitted(mcx_engine* e, const char* user_src, mcx_module_desc* d, const mcx_table* cdf, const mcx_table* t0,
+                             const mcx_table* t1, uint32_t pad_bytes, mcx_module** out);
 
 /* ------------------------------------------------------------------------------------------
  * Integration -- replaces _core.MonteCarloIntegrator.integrate (src/lib.rs:47-141) and

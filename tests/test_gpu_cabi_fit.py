@@ -1,8 +1,9 @@
-"""include/mcx.h: mcx_module_desc_fit / mcx_module_build_fitted -- libmcx's own performance planning of a call, for callers of
-the C ABI (which field of mcx_module_desc to set for which tables). The Python host layer makes the same decisions for its
-own calls (wgpu_montecarlo/api.py); here the two are held to the same desc, byte for byte, on the BASELINE workloads and on
-tables that take the other branches (no cell form, too large for LDS, user tables, random-walk proposals)."""
-import ctypes as C
+"""include/mcx.h: mcx_module_desc_fit / mcx_module_desc_fit_host / mcx_module_build_fitted -- libmcx's own performance planning
+of a call: which field of mcx_module_desc to set for which tables. The Python host layer calls it for its own plans
+(wgpu_montecarlo/api.py, _core.py), a C binding calls it directly (tests/cabi_client.c). Here: the plan made from resident
+tables and the plan made without a device (from mcx_table_analyse alone: MonteCarloIntegrator.planner()) are the same desc, byte
+for byte, on the BASELINE workloads -- the GPU-less build step compiles exactly the modules the GPU call loads --, and the
+branches those workloads do not take (no cell form, too large for LDS, user tables, random-walk proposals)."""
 import sys
 from pathlib import Path
 
@@ -13,33 +14,26 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
 
 
-def _refit(plan_desc, rt, cdf, t0, t1, p1, p2):
-    """A copy of the plan's desc with every planned field cleared, then fitted by libmcx."""
-    d = rt.ModuleDesc.from_buffer_copy(bytes(plan_desc))
-    d.cell_tables = d.cell_noclamp = d.cell_addr16 = d.cdf_direct = d.unit_params = 0
-    d.tables_lds = 1
-    if plan_desc.block == 512:
-        d.block = 0                      # the planner's own choice; an explicit workgroup size (MCMC shards) stays
-    rt.module_desc_fit(d, cdf, t0, t1, p1, p2)
-    return d
-
-
 def _fields(d):
     return {name: getattr(d, name) for name, _ in d._fields_}
 
 
 @pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
-def test_libmcx_fits_the_baseline_configs_like_the_python_planner(integrator, name):
+def test_the_plan_without_a_device_is_the_plan_on_the_gpu(integrator, name):
     import baseline_configs as bc
-    from wgpu_montecarlo import Distribution
+    from wgpu_montecarlo import Distribution, MonteCarloIntegrator
     from wgpu_montecarlo import runtime as rt
 
     wl = bc.get(name, Distribution)
     plan = wl.prepare(integrator)._plan
+    host = wl.prepare(MonteCarloIntegrator.planner())._plan
+    got = plan.desc
+    assert _fields(host.desc) == _fields(got) and host.module.key == rt.module_key(plan.module.user_src, got)
     tb = plan.tables
     pair = (tb.get("target_logpdf"), tb.get("proposal_logpdf")) if plan.kind == "mcmc" else (tb.get("target_pdf"), tb.get("proposal_pdf"))
-    got = _refit(plan.desc, rt, tb.get("cdf"), pair[0], pair[1], plan.p1, plan.p2)
-    assert _fields(got) == _fields(plan.desc)
+    again = rt.ModuleDesc.from_buffer_copy(bytes(got))                         # fitting a fitted desc changes nothing
+    rt.module_desc_fit(again, tb.get("cdf"), pair[0], pair[1], plan.p1, plan.p2)
+    assert _fields(again) == _fields(got)
     if name == "c3":
         assert got.cell_tables and got.cell_noclamp and got.block == 512 and got.tables_lds
     if name == "c4":

@@ -70,7 +70,7 @@ def test_c4_full_size(rng, sigmas):
     independence sampler, E[x] = 0 and E[x^2] = 5 of the bimodal target within the batch-means band."""
     wl = _wl("c4")
     res = wl.blocking(_mc(rng), 1_048_576, 42)
-    assert res.meta["block"] == 512           # a 22 KiB log-PDF table: api._fit_tables
+    assert res.meta["block"] == 512           # a 22 KiB log-PDF table: mcx_module_desc_fit
     assert res.meta["n_eff"] == 1_048_576 * 10_000 and res.n_samples == 1_048_576 * 10_000
     assert res.meta["n_blocks"] * res.meta["block"] == 1_048_576
     assert abs(res.meta["accept_rate"] - 0.6616) < 2e-3

@@ -214,7 +214,7 @@ def test_importance_sampling_nearly_uniform_grid(math_mode):
     ok, msg = close(res.values, ref["sums"] / ref["n_eff"], tol=2e-6 if math_mode == "precise" else TOL)
     assert ok, msg
     assert abs(res.values[1] - 1.0) < 0.02
-    assert not mc._cell_tables(mc._table(rt.TABLE_PDF, target._x_table, target._pdf_table))
+    assert not mc._table(rt.TABLE_PDF, target._x_table, target._pdf_table).has_cells
 
 
 def test_cell_tables_module_rejects_a_table_without_cells(integrator):

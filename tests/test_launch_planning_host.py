@@ -133,7 +133,7 @@ def test_custom_sampler_reach_is_known_only_when_draws_stay_inside_the_x_column(
 
 
 def test_table_facts_match_what_the_planner_needs():
-    """mcx_table_analyse (no GPU): the figures api._fit_tables decides with -- C3's 512-point PDF table, C4's 2048-point
+    """mcx_table_analyse (no GPU): the figures mcx_module_desc_fit decides with -- C3's 512-point PDF table, C4's 2048-point
     log-PDF table, Beta(2,5)'s 2048-point CDF table."""
     from wgpu_montecarlo import Distribution
 

@@ -106,7 +106,7 @@ def test_planner_builds_the_baseline_modules_without_a_gpu_and_cannot_launch():
 
 
 def test_lds_decisions_are_rechecked_against_the_code_objects_real_static_lds(monkeypatch):
-    """ADVICE r2: _fit_tables decides cell_addr16 / cell_noclamp / tables_lds with an upper bound of the kernel's static LDS;
+    """ADVICE r2: mcx_module_desc_fit decides cell_addr16 / cell_noclamp / tables_lds with an upper bound of the kernel's static LDS;
     the launch checks the real figure and refuses. If the real figure were ever larger, the plan must fall back to the
     slower form instead of turning a valid call into MCX_E_INVALID: simulated here with modules that report more."""
     xs = np.linspace(0, 10, 512)

@@ -157,13 +157,6 @@ def _analytic_logpdf(name: str, code: int, p1: float, p2: float) -> str:
     return f"MCX_DEV float {name}(float x) {{ return {body}; }}"
 
 
-def _unit_params(code: int, p1: float, p2: float) -> bool:
-    """normal(0,1) / uniform(0,1) / exponential(1): the sampler's affine map is specialised away (as api._unit_params)."""
-    if code in (runtime.DIST_NORMAL, runtime.DIST_UNIFORM):
-        return p1 == 0.0 and p2 == 1.0
-    return code == runtime.DIST_EXPONENTIAL and p1 == 1.0
-
-
 def _f32(a) -> Optional[np.ndarray]:
     """numpy inputs are copied as f32; a non-contiguous array silently becomes empty in the reference
     (`as_slice().unwrap_or(&[])`, src/lib.rs:71-77) -- here it is simply made contiguous."""
@@ -239,31 +232,14 @@ class MonteCarloIntegrator:
         _SOURCES[key] = "\n\n".join(parts)
         return _SOURCES[key]
 
-    def _fitted_module(self, src: str, desc, code: int, p1: float, p2: float, cdf, *tables, pads: bool = True):
-        """The module of `desc` with the table decisions api.py makes for the same call: cell form on strict grids, the
-        sentinel pads that spare the index clamp, LDS staging within the budget -- then held against the code object's real
-        static LDS (api.MonteCarloIntegrator._build_module)."""
+    def _fitted_module(self, src: str, desc, p1: float, p2: float, cdf, t0=None, t1=None):
+        """The module of `desc` with libmcx's own table decisions for the call (mcx_module_desc_fit: cell form on strict grids, the
+        sentinel pads that spare the index clamp, LDS staging within the budget, bucket-direct sampling) -- then held against the
+        code object's real static LDS, exactly as api.py builds its plans."""
         from . import api
 
-        live = [t for t in tables if t is not None]
-        desc.cell_tables = int(bool(live) and all(t.has_cells for t in live))
-        pad_bytes = None
-        if desc.cell_tables and pads and not os.environ.get("MCX_NO_NOCLAMP"):
-            total = 0
-            for t in live:
-                pp = runtime.cell_pads(t, code, p1, p2, cdf, True)
-                if pp is None:
-                    total = None
-                    break
-                total += 8 * sum(pp)
-            pad_bytes = total
-        desc.cell_noclamp = int(pad_bytes is not None)
-        api.MonteCarloIntegrator._fit_tables(desc, cdf, *tables, extra_bytes=pad_bytes or 0)
-        return api.build_module(self._engine, src, desc, cdf, *tables, extra_bytes=pad_bytes or 0)
-
-    def _cdf_direct(self, cdf, k: int) -> bool:
-        return (cdf is not None and cdf.direct_bits > 0 and k <= int(os.environ.get("MCX_DIRECT_MAX_ROWS", "32"))
-                and not os.environ.get("MCX_NO_DIRECT"))
+        pad_bytes = runtime.module_desc_fit(desc, cdf, t0, t1, p1, p2)
+        return api.build_module(self._engine, src, desc, cdf, t0, t1, extra_bytes=pad_bytes)
 
     def _integrate(self, functions, dist_type, dist_params, n_samples, seed, x_table, cdf_table, target, proposal, target_threads):
         """integrate / integrate_is_tables: `target` / `proposal` = (x, pdf) tables or None."""
@@ -282,9 +258,8 @@ class MonteCarloIntegrator:
             q_sampler = q_tab is None and code == runtime.DIST_NORMAL and _is_normal_pdf_text(split[2], p1, p2)
             src = self._weighted_source((split[0], split[1], None if q_sampler else split[2]), k)
             desc = runtime.make_desc(runtime.KIND_INTEGRATE, k, code, weight=True, p_table=p_tab is not None, q_table=q_tab is not None,
-                                     guard_endpoints=True, unit_params=_unit_params(code, p1, p2), q_sampler=q_sampler,
-                                     cdf_direct=self._cdf_direct(cdf, k))
-            mod = self._fitted_module(src, desc, code, p1, p2, cdf, p_tab, q_tab)
+                                     guard_endpoints=True, q_sampler=q_sampler)
+            mod = self._fitted_module(src, desc, p1, p2, cdf, p_tab, q_tab)
             sums, n_eff = self._engine.integrate(mod, int(n_samples), int(seed), p1, p2, target_threads, cdf=cdf,
                                                  target_pdf=p_tab, proposal_pdf=q_tab)
             return self._result(sums, k, n_eff)
@@ -300,10 +275,9 @@ class MonteCarloIntegrator:
             mod = self._engine.module(src, desc)
         else:
             desc = runtime.make_desc(runtime.KIND_INTEGRATE, k, code, guard_endpoints=True, user_tables=mask,
-                                     unit_params=_unit_params(code, p1, p2), cdf_direct=self._cdf_direct(cdf, k),
                                      moment_family=mask == 0 and k <= 32 and _moment_family(functions))
-            # user functions may look the tables up at any argument, not only at the draw: the index clamp stays (pads=False)
-            mod = self._fitted_module(src, desc, code, p1, p2, cdf, p_tab, q_tab, pads=False)
+            # (user functions may look the tables up at any argument, not only at the draw: with user_tables the index clamp stays)
+            mod = self._fitted_module(src, desc, p1, p2, cdf, p_tab, q_tab)
         sums, n_eff = self._engine.integrate(mod, int(n_samples), int(seed), p1, p2, target_threads, cdf=cdf, **tables)
         return self._result(sums, k, n_eff)
 
@@ -360,8 +334,8 @@ class MonteCarloIntegrator:
             padded = runtime.mcmc_dispatch_config(int(n_chains), target_threads).total_threads
             hint = runtime.mcmc_block_hint(padded)
             desc = runtime.make_desc(runtime.KIND_MCMC, len(functions), code, guard_endpoints=True, logpdf_analytic=analytic,
-                                     unit_params=_unit_params(code, p1, p2), q_sampler=q_sampler, block=0 if hint >= 1024 else hint)
-            mod = self._fitted_module(src, desc, code, p1, p2, cdf, t, q)
+                                     q_sampler=q_sampler, block=0 if hint >= 1024 else hint)
+            mod = self._fitted_module(src, desc, p1, p2, cdf, t, q)
         sums, n_eff = self._engine.mcmc(mod, int(n_steps), int(n_chains), int(n_burnin), int(seed), p1, p2, t, q,
                                         target_threads=target_threads, cdf=cdf)
         return self._result(sums, len(functions), n_eff)

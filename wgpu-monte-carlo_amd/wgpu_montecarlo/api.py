@@ -127,7 +127,7 @@ def functions_to_hip(functions: Sequence[FunctionLike], math="default") -> str:
 
 def build_module(engine, user_src: str, desc, *tables: Optional[runtime.Table], extra_bytes: int = 0):
     """Build (or fetch) the module for `desc`, then hold the plan-time LDS decisions against the code object's REAL
-    static LDS (the launch checks it: csrc/mcx_runtime.cpp integrate_impl / mcmc_impl). _fit_tables decided with an
+    static LDS (the launch checks it: csrc/mcx_runtime.cpp integrate_impl / mcmc_impl). mcx_module_desc_fit decided with an
     upper bound; should the real figure ever be larger, a default-on optimisation (staged tables, cell_noclamp,
     cell_addr16) must fall back to the slower form, not turn a valid call into MCX_E_INVALID. Shared with the
     `_core` binding (_core.py)."""
@@ -241,13 +241,6 @@ def _is_factory_normal(dist: Distribution, mean: float, std: float) -> bool:
         return float(cells["mean"]) == mean and float(cells["sigma"]) == std and std > 0.0
     except (KeyError, TypeError, ValueError):
         return False
-
-
-def _unit_params(code: int, p1: float, p2: float) -> bool:
-    """normal(0,1) / uniform(0,1) / exponential(1): the sampler's affine map is the identity and is specialised away."""
-    if code == runtime.DIST_NORMAL or code == runtime.DIST_UNIFORM:
-        return p1 == 0.0 and p2 == 1.0
-    return code == runtime.DIST_EXPONENTIAL and p1 == 1.0
 
 
 def _default_device() -> int:
@@ -406,54 +399,8 @@ class MonteCarloIntegrator:
             raise ValueError("custom distribution has no CDF table")
         return self._table(runtime.TABLE_CDF, dist._cdf_table, dist._x_table)
 
-    @staticmethod
-    def _fit_tables(desc, *tables: Optional[runtime.Table], extra_bytes: int = 0):
-        """Decide desc.tables_lds: do the staged forms of these tables fit next to the module's static LDS (its
-        reduction scratch)? Same budget libmcx checks at launch (mcx_lds_table_budget). When they do not fit, the
-        module is built with tables_lds = 0 and the same code reads the tables from HBM / L2."""
-        need = sum(tb.lds_bytes for tb in tables if tb is not None)
-        budget = runtime.lds_table_budget(desc)
-        # the sentinel cells of cell_noclamp are only worth staging while they cost no occupancy: within the budget, and not
-        # across the half-CU line (two workgroups per CU) when the bare tables are below it
-        half = budget - runtime.LDS_PER_CU // 2
-        if desc.cell_noclamp and (need + extra_bytes > budget or need <= half < need + extra_bytes):
-            desc.cell_noclamp = 0
-        if desc.cell_noclamp:
-            need += extra_bytes
-        desc.tables_lds = 1
-        # everything within 64 KiB of LDS (static scratch included: LDS_PER_CU - budget): a cell's byte address fits 16 bits
-        # and comes out of the index FMA's mantissa. Measured: C4 8.60 -> 8.52 ms; C3 0.624 -> 0.632 ms (slower, although it
-        # trades a half-rate convert for a full-rate shift) -- MCMC modules only (profiles/r02b_cell_addr16_ab.txt)
-        desc.cell_addr16 = int(desc.kind == runtime.KIND_MCMC and bool(desc.cell_tables) and need > 0
-                               and need + (runtime.LDS_PER_CU - budget) <= 65536 and not os.environ.get("MCX_NO_ADDR16"))
-        if need > budget:
-            desc.tables_lds = 0
-            desc.cdf_direct = 0            # the bucket-direct records only pay from LDS
-            desc.cell_noclamp = 0          # and so does the padded cell array
-        elif (not desc.block and need > 0 and desc.dist_type != runtime.DIST_CUSTOM and 4 * need <= budget
-              and not os.environ.get("MCX_BLOCK")):
-            # libmcx's default for table kernels is 1024 threads (more waves share one staged copy -- what K = 32 on a
-            # 72 KiB CDF table needs). Small PDF / log-PDF tables, of which four copies fit a CU, run better with 512:
-            # C3 0.662 -> 0.629 ms, C4 8.65 -> 8.51 ms (256: 0.666 / 8.50; profiles/r02b_flush_period_and_block_size_sweep.txt)
-            desc.block = 512
-        return desc
-
     def _build_module(self, user_src: str, desc, *tables: Optional[runtime.Table], extra_bytes: int = 0):
         return build_module(self._engine, user_src, desc, *tables, extra_bytes=extra_bytes)
-
-    def _cell_pads(self, cell_tables: bool, code: int, p1: float, p2: float, cdf, *tables) -> Optional[int]:
-        """desc.cell_noclamp: can every cell table of the call be padded over the sampler's range (then the lookup needs
-        no index clamp)? Returns the extra LDS bytes, or None when not (no cell tables, unbounded or too wide a range)."""
-        tables = [t for t in tables if t is not None]
-        if not cell_tables or not tables or os.environ.get("MCX_NO_NOCLAMP"):
-            return None
-        total = 0
-        for t in tables:
-            pads = runtime.cell_pads(t, code, p1, p2, cdf, self._guard)
-            if pads is None:
-                return None
-            total += 8 * sum(pads)
-        return total
 
     def _replicas(self, plan: "_Plan"):
         """[(engine, module, tables)] of a plan on every device of this integrator (built on first use). Plans are cached per
@@ -534,22 +481,6 @@ class MonteCarloIntegrator:
         every function per sample."""
         return not self._std_error and self._math != "precise" and _moment_family(functions)
 
-    def _cell_tables(self, *tables) -> bool:
-        """Compile the one-read-one-FMA lookup when every PDF / log-PDF table of the call is a strict grid."""
-        tables = [t for t in tables if t is not None]
-        return bool(tables) and not self._precise_sampler and all(t.has_cells for t in tables)
-
-    def _cdf_direct(self, cdf: Optional[runtime.Table], k: int) -> bool:
-        """Sample a custom distribution through the bucket-direct form of its CDF table (one read + one FMA for draws
-        whose bucket holds no cdf node, the rest resolved in batches) when the table has one; math="precise" keeps the
-        reference's search + blend. Both streams. Measured on Beta(2,5), 2e9 samples, warm device, against the guided search:
-        1.40 / 1.65 ms at K = 4, 1.77 / 1.99 ms at K = 16, 2.48 / 2.62 ms at K = 32 on the reference stream (from 12 rows
-        the kernel's queue is an exchange ring, so that no lane sits the evaluation out), 1.60 / 1.88 and 2.70 / 2.85 ms at
-        K = 4 / 32 on Philox (profiles/r02b_moment_family_and_direct_sampler_ab.txt). Up to 32 accumulator rows."""
-        rows = k * (2 if self._std_error else 1)
-        return (cdf is not None and cdf.direct_bits > 0 and not self._precise_sampler
-                and rows <= int(os.environ.get("MCX_DIRECT_MAX_ROWS", "32")) and not os.environ.get("MCX_NO_DIRECT"))
-
     def _rank_world(self):
         return (self._group.rank, self._group.world) if self._group is not None else (0, 1)
 
@@ -564,9 +495,8 @@ class MonteCarloIntegrator:
         k = len(functions)
         desc = runtime.make_desc(runtime.KIND_INTEGRATE, k, code, guard_endpoints=self._guard,
                                  precise_sampler=self._precise_sampler, rng=rng,
-                                 second_moments=self._std_error, unit_params=_unit_params(code, p1, p2),
-                                 moment_family=self._use_moment_family(functions), cdf_direct=self._cdf_direct(cdf, k))
-        self._fit_tables(desc, cdf)
+                                 second_moments=self._std_error, moment_family=self._use_moment_family(functions))
+        runtime.module_desc_fit(desc, cdf, None, None, p1, p2)
         return _Plan("integrate", self._build_module(user_src, desc, cdf), desc, k, runtime.result_rows(desc), p1, p2,
                      dict(cdf=cdf))
 
@@ -595,17 +525,13 @@ class MonteCarloIntegrator:
         elif not q_sampler:
             user_src += "\n\n" + q_src
         k = len(functions)
-        cells = self._cell_tables(p_table, q_table)
-        pad_bytes = self._cell_pads(cells, code, p1, p2, cdf, p_table, q_table)
         desc = runtime.make_desc(runtime.KIND_INTEGRATE, k, code, weight=True,
                                  p_table=p_table is not None, q_table=q_table is not None,
                                  guard_endpoints=self._guard, precise_sampler=self._precise_sampler,
-                                 rng=rng, second_moments=self._std_error,
-                                 unit_params=_unit_params(code, p1, p2),
-                                 cell_tables=cells, q_sampler=q_sampler, cell_noclamp=pad_bytes is not None,
-                                 moment_family=self._use_moment_family(functions), cdf_direct=self._cdf_direct(cdf, k))
-        self._fit_tables(desc, cdf, p_table, q_table, extra_bytes=pad_bytes or 0)
-        return _Plan("integrate", self._build_module(user_src, desc, cdf, p_table, q_table, extra_bytes=pad_bytes or 0), desc, k,
+                                 rng=rng, second_moments=self._std_error, q_sampler=q_sampler,
+                                 moment_family=self._use_moment_family(functions))
+        pad_bytes = runtime.module_desc_fit(desc, cdf, p_table, q_table, p1, p2)       # cell form, pads, LDS staging, block: libmcx decides
+        return _Plan("integrate", self._build_module(user_src, desc, cdf, p_table, q_table, extra_bytes=pad_bytes), desc, k,
                      runtime.result_rows(desc), p1, p2, dict(cdf=cdf, target_pdf=p_table, proposal_pdf=q_table))
 
     def _mcmc_block(self, n_chains: int, parts: Optional[int] = None) -> int:
@@ -650,15 +576,13 @@ class MonteCarloIntegrator:
                     raise ValueError("adaptive_random_walk needs increments symmetric about 0: normal(0, s) or uniform(-w, w)")
                 walk = runtime.WALK_ADAPTIVE
         k = len(functions)
-        cells = self._cell_tables(t_table, q_table)
-        # independent proposals: every lookup is at a draw of the proposal, whose range is known -> no index clamp
-        pad_bytes = self._cell_pads(cells, code, p1, p2, cdf, t_table, q_table) if walk == runtime.WALK_INDEPENDENT else None
         desc = runtime.make_desc(runtime.KIND_MCMC, k, code, guard_endpoints=self._guard,
                                  precise_sampler=self._precise_sampler, rng=rng, block=block,
-                                 unit_params=_unit_params(code, p1, p2), second_moments=self._std_error, walk=walk,
-                                 cell_tables=cells, q_sampler=q_sampler, cell_noclamp=pad_bytes is not None)
-        self._fit_tables(desc, cdf, t_table, q_table, extra_bytes=pad_bytes or 0)
-        return _Plan("mcmc", self._build_module(user_src, desc, cdf, t_table, q_table, extra_bytes=pad_bytes or 0), desc, k,
+                                 second_moments=self._std_error, walk=walk, q_sampler=q_sampler)
+        # cell form, pads (independent proposals: every lookup is at a draw of the proposal, whose range is known), 16-bit LDS
+        # addresses, LDS staging, workgroup size: libmcx decides (mcx_module_desc_fit)
+        pad_bytes = runtime.module_desc_fit(desc, cdf, t_table, q_table, p1, p2)
+        return _Plan("mcmc", self._build_module(user_src, desc, cdf, t_table, q_table, extra_bytes=pad_bytes), desc, k,
                      runtime.result_rows(desc), p1, p2,
                      dict(cdf=cdf, target_logpdf=t_table, proposal_logpdf=q_table), x0=float(initial_state),
                      target_accept=float(target_accept), proposal_kind=proposal_kind, walk=walk)

@@ -94,7 +94,7 @@ EXPORTED_SYMBOLS = [
     "mcx_comm_create", "mcx_comm_destroy", "mcx_comm_size", "mcx_integrate_comm", "mcx_mcmc_comm",
     "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct", "mcx_mcmc_block_hint", "mcx_cell_pads", "mcx_cell_pads_host", "mcx_default_launch_blocks", "mcx_engine_set_mcmc_segments",
     "mcx_abi_version", "mcx_module_key", "mcx_table_analyse", "mcx_table_facts_of", "mcx_engine_last_call", "mcx_module_block",
-    "mcx_module_desc_fit", "mcx_module_build_fitted",
+    "mcx_module_desc_fit", "mcx_module_build_fitted", "mcx_module_desc_fit_host",
 ]
 
 _lib = None
@@ -170,6 +170,8 @@ def load():
         L.mcx_module_precompile.argtypes = [C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(C.c_int)]
         L.mcx_module_desc_fit.argtypes = [C.POINTER(ModuleDesc), vp, vp, vp, C.c_float, C.c_float, C.POINTER(u32)]
         L.mcx_module_build_fitted.argtypes = [vp, C.c_char_p, C.POINTER(ModuleDesc), vp, vp, vp, u32, C.POINTER(vp)]
+        L.mcx_module_desc_fit_host.argtypes = [C.POINTER(ModuleDesc), C.POINTER(TableFacts), C.POINTER(TableFacts), C.POINTER(C.c_float),
+                                               C.POINTER(TableFacts), C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(u32)]
         L.mcx_result_rows.argtypes = [C.POINTER(ModuleDesc)]
         L.mcx_module_source.argtypes = [C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(vp)]
         L.mcx_free.argtypes = [vp]
@@ -297,13 +299,22 @@ def make_desc(kind: int, k: int, dist_type: int, weight: bool = False, p_table: 
                       int(cdf_direct), int(cell_noclamp), int(cell_addr16))
 
 
-def module_desc_fit(desc: ModuleDesc, cdf: Optional["Table"], t0: Optional["Table"], t1: Optional["Table"], p1: float, p2: float) -> int:
-    """libmcx's own performance planning of one call (include/mcx.h: mcx_module_desc_fit): fills cell_tables, cell_noclamp,
-    cell_addr16, tables_lds, cdf_direct, unit_params and block of `desc` in place; returns the LDS bytes of the sentinel pads.
-    What api.py decides for its own calls in Python -- tests/test_gpu_cabi_fit.py holds the two to the same desc."""
+def module_desc_fit(desc: ModuleDesc, cdf, t0, t1, p1: float, p2: float) -> int:
+    """libmcx's performance planning of one call (include/mcx.h: mcx_module_desc_fit / mcx_module_desc_fit_host): which table
+    forms, LDS staging and workgroup size the call gets. Fills cell_tables, cell_noclamp, cell_addr16, tables_lds, cdf_direct,
+    unit_params and block of `desc` in place; returns the LDS bytes of the sentinel pads. Tables are resident ones (Table) or, for
+    a planner without a device, HostTables."""
     pad = C.c_uint32(0)
-    h = lambda t: t._h if t is not None else None
-    check(load().mcx_module_desc_fit(C.byref(desc), h(cdf), h(t0), h(t1), float(p1), float(p2), C.byref(pad)))
+    live = [t for t in (cdf, t0, t1) if t is not None]
+    if live and all(isinstance(t, HostTable) for t in live):
+        fp = C.POINTER(C.c_float)
+        facts = lambda t: C.byref(t.facts) if t is not None else None
+        keys = lambda t: t.keys.ctypes.data_as(fp) if t is not None else None
+        check(load().mcx_module_desc_fit_host(C.byref(desc), facts(cdf), facts(t0), keys(t0), facts(t1), keys(t1), float(p1), float(p2),
+                                              C.byref(pad)))
+    else:
+        h = lambda t: t._h if t is not None else None
+        check(load().mcx_module_desc_fit(C.byref(desc), h(cdf), h(t0), h(t1), float(p1), float(p2), C.byref(pad)))
     return int(pad.value)
 
 
@@ -508,6 +519,7 @@ class HostTable:
         if keys.shape != values.shape or keys.ndim != 1:
             raise ValueError("table keys and values must be 1D arrays of the same length")
         f = table_facts(kind, keys, values)
+        self.facts = f
         self.kind, self.n, self.keys, self.values = kind, len(keys), keys, values
         self.has_cells, self.direct_bits, self.lds_bytes = f.has_cells == 1, int(f.direct_bits), int(f.lds_bytes)
         self.reach_known = f.reach_known == 1
