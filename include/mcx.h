@@ -27,6 +27,7 @@ extern "C" {
 #define MCX_E_RUNTIME      -2   /* HIP runtime failure (RuntimeError)                           */
 #define MCX_E_COMPILE      -3   /* hiprtc failure, log in mcx_last_error() (RuntimeError)       */
 #define MCX_E_NODEVICE     -4   /* no usable GPU (RuntimeError "Failed to initialize GPU: ..")  */
+#define MCX_E_TRANSLATE    -5   /* a WGSL function string outside the translator's subset (TranspilerError) */
 
 /* distribution type codes: DistributionParamsBuffer.dist_type, src/engine.rs:32-37, src/lib.rs:436-502 */
 #define MCX_DIST_UNIFORM     0
@@ -281,6 +282,19 @@ uint32_t mcx_module_static_lds(const mcx_module* m);
  * scratch its kernel declares. A call whose tables (sum of mcx_table_lds_bytes) exceed it must build the module with
  * tables_lds = 0; launches check the exact figure. 0 for an invalid desc. */
 uint32_t mcx_lds_table_budget(const mcx_module_desc* desc);
+/* ------------------------------------------------------------------------------------------
+ * WGSL function strings -- what the reference's native half is handed (src/lib.rs:47-59: `functions: Vec<String>`, the output of its
+ * Python transpiler, user-written strings and its importance-sampling wrappers, python/wgpu_montecarlo/__init__.py:740-742, 893-905,
+ * 968-980) and splices into its shader (src/shader_gen.rs:45-128). libmcx's kernels are HIP: mcx_wgsl_translate turns one such string
+ * (entry function first, helpers after it; the scalar subset: f32 / i32 / u32 / bool, let / var / const, if / else, for / while / loop,
+ * the WGSL builtins, calls to pdf_target_from_table / pdf_proposal_from_table -> desc.user_tables) into the `MCX_DEV` functions
+ * mcx_module_build takes as user_src: the entry is named `entry_name` (user_func_<i>, mcx_pdf_p, ...), helpers are prefixed
+ * mcx_uf<slot>_. math: 0 = ocml builtins, 1 = the hardware forms within WGSL's own accuracy bounds (device/mcx_device.hpp: mcx_sin ..),
+ * 2 = additionally the bare v_sin / v_cos. user_src = mcx_wgsl_prelude() + the translations. *out_text: mcx_free. Needs no GPU.
+ * ------------------------------------------------------------------------------------------ */
+int  mcx_wgsl_translate(const char* wgsl, int32_t slot, const char* entry_name, int32_t math, char** out_text);
+const char* mcx_wgsl_prelude(void);
+
 /* Where code objects are cached (default: <dir of libmcx.so>/jit_cache, override MCX_CACHE_DIR). The in-memory copy
  * is an LRU of MCX_CODE_CACHE_ENTRIES (default 256) code objects. */
 const char* mcx_cache_dir(void);

@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
     LOAD(mcx_hip_runtime) LOAD(mcx_comm_create) LOAD(mcx_comm_destroy) LOAD(mcx_comm_size) LOAD(mcx_integrate_comm)
     LOAD(mcx_rccl_library) LOAD(mcx_lds_table_budget) LOAD(mcx_module_static_lds) LOAD(mcx_engine_last_launch_count)
     LOAD(mcx_abi_version) LOAD(mcx_result_rows) LOAD(mcx_table_create) LOAD(mcx_table_release) LOAD(mcx_module_desc_fit)
-    LOAD(mcx_module_build_fitted) LOAD(mcx_module_block)
+    LOAD(mcx_module_build_fitted) LOAD(mcx_module_block) LOAD(mcx_wgsl_translate) LOAD(mcx_wgsl_prelude) LOAD(mcx_free)
 
     printf("OK version %s\n", p_mcx_version());
     mcx_dispatch d;
@@ -74,6 +74,21 @@ int main(int argc, char** argv) {
         if (p_mcx_result_rows(&longer.d) != MCX_E_INVALID || !strstr(p_mcx_last_error(), "newer mcx.h")) return 1;
         longer.d.struct_size = 0u;
         if (p_mcx_result_rows(&longer.d) != MCX_E_INVALID || !strstr(p_mcx_last_error(), "struct_size is 0")) return 1;
+    }
+    {   /* the reference's own payload format: WGSL text in (what its transpiler writes for x**2 and a user string with a helper) */
+        char *f0 = NULL, *f1 = NULL;
+        if (p_mcx_wgsl_translate("fn user_func_9b8538e9(x: f32) -> f32 {\n    return pow(x, 2.0);\n}", 0, "user_func_0", 1, &f0) ||
+            p_mcx_wgsl_translate("fn g(x: f32) -> f32 { return twice(sin(x)) ; }\nfn twice(y: f32) -> f32 { return 2.0 * y; }", 1, "user_func_1", 1, &f1)) {
+            fprintf(stderr, "wgsl: %s\n", p_mcx_last_error()); return 1;
+        }
+        if (!strstr(f0, "McxPowI<2>::of(x)") || !strstr(f1, "mcx_uf1_twice(mcx_sin(x))") || !strstr(p_mcx_wgsl_prelude(), "struct McxPowI")) {
+            fprintf(stderr, "wgsl text:\n%s\n%s\n", f0, f1); return 1;
+        }
+        char* none = NULL;
+        if (p_mcx_wgsl_translate("fn f(x: vec2<f32>) -> f32 { return 1.0; }", 0, "user_func_0", 0, &none) != MCX_E_TRANSLATE ||
+            !strstr(p_mcx_last_error(), "unsupported type 'vec2'")) return 1;
+        printf("OK wgsl translated: %u + %u bytes of HIP\n", (unsigned)strlen(f0), (unsigned)strlen(f1));
+        p_mcx_free(f0); p_mcx_free(f1);
     }
     printf("OK abi version %u, desc of %u bytes (library: %u)\n", p_mcx_abi_version(), (unsigned)sizeof desc, (unsigned)sizeof(mcx_module_desc));
 

@@ -1,18 +1,15 @@
 #!/usr/bin/env python3
 """BASELINE C2 (K = 4 moments on N(0,1)) through the `_core` binding -- the reference's transpiler text, `pow(x, 2.0)` .. `pow(x, 4.0)`,
-translated by wgsl_to_hip.py -- against this package's own API, blocking calls. `--pow-calls` restores the literal translation
-(`powf(x, 2.0f)`), what the binding compiled before whole literal exponents became product chains.
-    python tools/core_vs_api.py [--pow-calls]
+translated by libmcx (mcx_wgsl_translate) -- against this package's own API, blocking calls. (The "before" rows of
+profiles/r03_core_binding_c2.txt, with every pow(x, k.0) a powf call, were measured at commit 0d76349.)
+    python tools/core_vs_api.py
 """
 import sys
 import time
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "wgpu-monte-carlo_amd"))
-from wgpu_montecarlo import Distribution, MonteCarloIntegrator, _core, transpile_function, wgsl_to_hip  # noqa: E402
-
-if "--pow-calls" in sys.argv:
-    wgsl_to_hip._whole_exponent = lambda text: None
+from wgpu_montecarlo import Distribution, MonteCarloIntegrator, _core, transpile_function  # noqa: E402
 
 fns = [lambda x: x, lambda x: x**2, lambda x: x**3, lambda x: x**4]
 texts = [transpile_function(f) for f in fns]

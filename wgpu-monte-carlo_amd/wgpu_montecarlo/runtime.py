@@ -94,7 +94,7 @@ EXPORTED_SYMBOLS = [
     "mcx_comm_create", "mcx_comm_destroy", "mcx_comm_size", "mcx_integrate_comm", "mcx_mcmc_comm",
     "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct", "mcx_mcmc_block_hint", "mcx_cell_pads", "mcx_cell_pads_host", "mcx_default_launch_blocks", "mcx_engine_set_mcmc_segments",
     "mcx_abi_version", "mcx_module_key", "mcx_table_analyse", "mcx_table_facts_of", "mcx_engine_last_call", "mcx_module_block",
-    "mcx_module_desc_fit", "mcx_module_build_fitted", "mcx_module_desc_fit_host",
+    "mcx_module_desc_fit", "mcx_module_build_fitted", "mcx_module_desc_fit_host", "mcx_wgsl_translate", "mcx_wgsl_prelude",
 ]
 
 _lib = None
@@ -168,6 +168,8 @@ def load():
         L.mcx_engine_set_mcmc_segments.argtypes = [vp, u32]
         L.mcx_module_build.argtypes = [vp, C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(vp)]
         L.mcx_module_precompile.argtypes = [C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(C.c_int)]
+        L.mcx_wgsl_translate.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(vp)]
+        L.mcx_wgsl_prelude.restype = C.c_char_p
         L.mcx_module_desc_fit.argtypes = [C.POINTER(ModuleDesc), vp, vp, vp, C.c_float, C.c_float, C.POINTER(u32)]
         L.mcx_module_build_fitted.argtypes = [vp, C.c_char_p, C.POINTER(ModuleDesc), vp, vp, vp, u32, C.POINTER(vp)]
         L.mcx_module_desc_fit_host.argtypes = [C.POINTER(ModuleDesc), C.POINTER(TableFacts), C.POINTER(TableFacts), C.POINTER(C.c_float),
