@@ -295,6 +295,38 @@ uint32_t mcx_lds_table_budget(const mcx_module_desc* desc);
 int  mcx_wgsl_translate(const char* wgsl, int32_t slot, const char* entry_name, int32_t math, char** out_text);
 const char* mcx_wgsl_prelude(void);
 
+/* A whole payload of the reference's native module -- the K strings of one call -- planned: what the strings ARE is visible in their
+ * text, and libmcx builds the better module for it (math != 0; math = 0 compiles every string literally as user_func_i):
+ *   - every string one of the importance-sampling wrappers the reference's Python half generates (`_is_wrapper_i`: f_val * p / q around
+ *     _is_f_orig_i, _is_pdf_p_i | pdf_target_from_table, _is_pdf_q_i | pdf_proposal_from_table; python/wgpu_montecarlo/__init__.py:
+ *     893-905, 968-980) around the same p and q: K integrands + ONE weight per sample (desc.weight, p_table / q_table, mcx_pdf_p /
+ *     mcx_pdf_q in the text); a q that is Distribution.normal's closure for exactly (param1, param2): desc.q_sampler;
+ *   - the transpiler's text for x, x**2, .., x**K (8 <= K <= 32): desc.moment_family;
+ *   - MCMC: a log-density without its table becomes the analytic one of its distribution type (desc.logpdf_analytic,
+ *     src/shader_gen.rs:543-571); a normal proposal takes log q from its own deviate (desc.q_sampler; its table is then not bound).
+ * Fills desc_out (initialised here; set desc.block / call mcx_module_desc_fit with the call's tables afterwards) and *user_src_out
+ * (mcx_free). Bind the target / proposal PDF tables as target_pdf / proposal_pdf in either case (desc.weight or desc.user_tables). */
+typedef struct mcx_wgsl_program {
+    uint32_t struct_size;          /* mcx_wgsl_program_init() */
+    int32_t  kind;                 /* MCX_KIND_INTEGRATE (integrate / integrate_is_tables) or MCX_KIND_MCMC */
+    int32_t  k;
+    const char* const* functions;  /* k WGSL strings */
+    int32_t  dist_type;            /* sampling / proposal distribution and its parameters */
+    float    param1, param2;
+    int32_t  math;                 /* 0 precise (literal), 1 default, 2 fast */
+    int32_t  have_target_table;    /* the call brings a target PDF (integrate) / log-PDF (MCMC) table */
+    int32_t  have_proposal_table;  /* likewise for the proposal */
+    int32_t  target_dist_type;     /* MCMC without a target table: the distribution whose analytic log-density is evaluated */
+    float    target_param1, target_param2;
+} mcx_wgsl_program;
+static inline void mcx_wgsl_program_init(mcx_wgsl_program* g) {
+    uint32_t i;
+    for (i = 0; i < sizeof(*g); ++i) ((unsigned char*)g)[i] = 0;
+    g->struct_size = (uint32_t)sizeof(*g);
+    g->math = 1;
+}
+int  mcx_wgsl_plan(const mcx_wgsl_program* prog, mcx_module_desc* desc_out, char** user_src_out);
+
 /* Where code objects are cached (default: <dir of libmcx.so>/jit_cache, override MCX_CACHE_DIR). The in-memory copy
  * is an LRU of MCX_CODE_CACHE_ENTRIES (default 256) code objects. */
 const char* mcx_cache_dir(void);

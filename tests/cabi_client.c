@@ -49,6 +49,7 @@ int main(int argc, char** argv) {
     LOAD(mcx_rccl_library) LOAD(mcx_lds_table_budget) LOAD(mcx_module_static_lds) LOAD(mcx_engine_last_launch_count)
     LOAD(mcx_abi_version) LOAD(mcx_result_rows) LOAD(mcx_table_create) LOAD(mcx_table_release) LOAD(mcx_module_desc_fit)
     LOAD(mcx_module_build_fitted) LOAD(mcx_module_block) LOAD(mcx_wgsl_translate) LOAD(mcx_wgsl_prelude) LOAD(mcx_free)
+    LOAD(mcx_wgsl_plan)
 
     printf("OK version %s\n", p_mcx_version());
     mcx_dispatch d;
@@ -165,6 +166,45 @@ int main(int argc, char** argv) {
         printf("OK fitted importance sampling: cells %d, %u pad bytes, block %u, E_p[x]=%.6f E_p[x^2]=%.6f kernel_ms=%.3f\n", wd.cell_tables,
                pad_bytes, p_mcx_module_block(wm), ws[0] / (double)wn, ws[1] / (double)wn, p_mcx_engine_last_kernel_ms(e));
         if (fabs(ws[0] / (double)wn) > 1.5e-3 || fabs(ws[1] / (double)wn - 1.0) > 3e-3) return 1;
+        /* the same call as the reference's Python half phrases it: two importance-sampling wrappers (python/wgpu_montecarlo/
+         * __init__.py:968-980) around pdf_target_from_table and Distribution.normal(0.5, 1.5)'s closure. mcx_wgsl_plan recognises them:
+         * K integrands + one weight, 1/q from the deviate -- the module above -- and the sums agree to rounding. */
+        static const char* W0 =
+            "\nfn _is_wrapper_0(x: f32) -> f32 {\n    let f_val = _is_f_orig_0(x);\n    let p = pdf_target_from_table(x);\n    let q = _is_pdf_q_0(x);\n"
+            "    return f_val * p / q;\n}\n\n\nfn _is_pdf_q_0(x: f32) -> f32 {\n    const mean: f32 = 0.5;\n    const sigma: f32 = 1.5;\n"
+            "    const sqrt_2pi: f32 = 2.5066282746310002;\n    var z = ((x - mean) / sigma);\n    return (exp((((-0.5) * z) * z)) / (sigma * sqrt_2pi));\n}\n"
+            "fn _is_f_orig_0(x: f32) -> f32 {\n    return x;\n}\n";
+        static const char* W1 =
+            "\nfn _is_wrapper_1(x: f32) -> f32 {\n    let f_val = _is_f_orig_1(x);\n    let p = pdf_target_from_table(x);\n    let q = _is_pdf_q_1(x);\n"
+            "    return f_val * p / q;\n}\n\n\nfn _is_pdf_q_1(x: f32) -> f32 {\n    const mean: f32 = 0.5;\n    const sigma: f32 = 1.5;\n"
+            "    const sqrt_2pi: f32 = 2.5066282746310002;\n    var z = ((x - mean) / sigma);\n    return (exp((((-0.5) * z) * z)) / (sigma * sqrt_2pi));\n}\n"
+            "fn _is_f_orig_1(x: f32) -> f32 {\n    return pow(x, 2.0);\n}\n";
+        const char* payload[2] = {W0, W1};
+        mcx_wgsl_program prog;
+        mcx_wgsl_program_init(&prog);
+        prog.kind = MCX_KIND_INTEGRATE; prog.k = 2; prog.functions = payload; prog.dist_type = MCX_DIST_NORMAL;
+        prog.param1 = 0.5f; prog.param2 = 1.5f; prog.have_target_table = 1;
+        mcx_module_desc pd;
+        char* planned = NULL;
+        if (p_mcx_wgsl_plan(&prog, &pd, &planned)) { fprintf(stderr, "plan: %s\n", p_mcx_last_error()); return 1; }
+        if (!pd.weight || !pd.p_table || pd.q_table || !pd.q_sampler || pd.user_tables || strstr(planned, "mcx_pdf_q")) {
+            fprintf(stderr, "plan: weight %d p_table %d q_sampler %d\n%s\n", pd.weight, pd.p_table, pd.q_sampler, planned); return 1;
+        }
+        uint32_t ppad = 0u;
+        mcx_module* pm = NULL;
+        if (p_mcx_module_desc_fit(&pd, NULL, t, NULL, 0.5f, 1.5f, &ppad) || p_mcx_module_build_fitted(e, planned, &pd, NULL, t, NULL, ppad, &pm)) {
+            fprintf(stderr, "planned module: %s\n", p_mcx_last_error()); return 1;
+        }
+        double ps2[2]; uint64_t pn = 0;
+        if (p_mcx_integrate(e, pm, &wp, ps2, &pn)) { fprintf(stderr, "planned integrate: %s\n", p_mcx_last_error()); return 1; }
+        printf("OK planned from the reference's wrapper text: E_p[x]=%.6f E_p[x^2]=%.6f (hand-built module: %.6f %.6f)\n", ps2[0] / (double)pn,
+               ps2[1] / (double)pn, ws[0] / (double)wn, ws[1] / (double)wn);
+        if (pn != wn || fabs(ps2[0] - ws[0]) > 1e-6 * (double)wn || fabs(ps2[1] - ws[1]) > 1e-6 * (double)wn) return 1;
+        prog.math = 0;                                  /* literal: two functions that read the table themselves */
+        char* literal = NULL;
+        if (p_mcx_wgsl_plan(&prog, &pd, &literal) || pd.weight || pd.user_tables != 1 || !strstr(literal, "mcx_user_pdf_target(x)")) return 1;
+        p_mcx_free(planned); p_mcx_free(literal);
+        p_mcx_module_release(pm);
         p_mcx_module_release(wm);
         p_mcx_table_release(t);
     }

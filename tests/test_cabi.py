@@ -17,7 +17,7 @@ HEADER = (ROOT / "include" / "mcx.h").read_text()
 def declared_symbols():
     names = set(re.findall(r"\b(mcx_[a-z0-9_]+)\s*\(", HEADER))
     inline = set(re.findall(r"static inline \w+ (mcx_[a-z0-9_]+)\s*\(", HEADER))      # the mcx_*_init helpers live in the header
-    assert inline == {"mcx_module_desc_init", "mcx_integrate_params_init", "mcx_mcmc_params_init"}
+    assert inline == {"mcx_module_desc_init", "mcx_integrate_params_init", "mcx_mcmc_params_init", "mcx_wgsl_program_init"}
     return sorted(names - inline)
 
 
@@ -276,41 +276,3 @@ def test_module_key_names_the_cached_code_object():
     rt.precompile(src, desc)
     assert (Path(rt.cache_dir()) / f"{key}.hsaco").exists()
     assert rt.module_key(src, rt.make_desc(rt.KIND_INTEGRATE, 1, rt.DIST_NORMAL)) != key
-
-
-def test_core_binding_recognises_the_references_importance_sampling_wrappers():
-    """`_core` (math != "precise") compiles the K wrappers the reference's Python half generates as K integrands + one weight
-    (wgpu_montecarlo/_core.py: _split_weighted). The recorded payloads are the reference's own text; anything else stays literal."""
-    import json
-    from pathlib import Path
-
-    from wgpu_montecarlo import _core
-
-    meta = json.loads((Path(__file__).resolve().parent / "golden" / "boundary_payloads.json").read_text())
-    wgsl = lambda i: meta[i]["args"][0]["wgsl"]
-    assert _core._split_weighted(wgsl(1)) is None                                   # plain integrands (C2)
-    f, p, q = _core._split_weighted(wgsl(2))                                        # C3: target from its table, analytic proposal
-    assert len(f) == 4 and p is None and q is not None and "_is_pdf_q(" in q and "_is_f_orig_3" in f[3] and "pow(x, 4.0)" in f[3]
-    assert _core._is_normal_pdf_text(q, 2.0, 3.0) and not _core._is_normal_pdf_text(q, 2.0, 3.5) and not _core._is_normal_pdf_text(None, 2.0, 3.0)
-    f, p, q = _core._split_weighted(wgsl(5))                                        # analytic target and proposal
-    assert len(f) == 1 and "_is_pdf_p(" in p and _core._is_normal_pdf_text(p, 0.0, 1.0) and _core._is_normal_pdf_text(q, 0.5, 1.5)
-    broken = list(wgsl(2))
-    broken[2] = broken[2].replace("sigma: f32 = 3.0", "sigma: f32 = 3.5")           # wrappers around different proposals: not one weight
-    assert _core._split_weighted(broken) is None
-    assert _core._split_weighted([wgsl(2)[0].replace("f_val * p / q", "f_val * p * q")]) is None
-    assert _core._split_weighted([wgsl(2)[0], "fn g(x: f32) -> f32 { return x; }"]) is None
-    helper = wgsl(2)[0] + "\nfn my_helper(y: f32) -> f32 { return y * 2.0; }\n"       # a user string with a helper after its entry
-    f, _, _ = _core._split_weighted([helper])
-    assert "my_helper" in f[0]
-
-
-def test_core_binding_recognises_the_fused_moments_workload():
-    from wgpu_montecarlo import _core, transpile_function
-
-    second = transpile_function(lambda x: x**2)                       # the transpiler's text for x**2 ...
-    assert "return pow(x, 2.0);" in second
-    texts = [transpile_function(lambda x: x)] + [second.replace("pow(x, 2.0)", f"pow(x, {k}.0)") for k in range(2, 33)]   # ... and for x**k
-    assert "return x;" in texts[0] and "pow(x, 32.0)" in texts[31]
-    assert _core._moment_family(texts) and _core._moment_family(texts[:8]) and not _core._moment_family(texts[:7])
-    assert not _core._moment_family(texts[1:]) and not _core._moment_family(texts[:9] + [texts[11]] + texts[10:])
-    assert not _core._moment_family(texts[:8] + ["fn f(x: f32) -> f32 { return pow(x, 9.0) + 0.0; }"])

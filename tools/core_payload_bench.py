@@ -49,7 +49,7 @@ def best(call, reps=3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--math", default="precise")
+    ap.add_argument("--math", default="default")
     ap.add_argument("--configs", default="c2,c3,c4,c5")
     args = ap.parse_args()
     calls = golden_calls()

@@ -14,6 +14,8 @@
 // expressions, and an integer quotient must stay one. A literal whole exponent -- `pow(x, 2.0)` is what the reference's
 // transpiler writes for x**2 -- becomes the product chain McxPowI<n> (prelude: mcx_wgsl_prelude()) in every mode.
 #include <cctype>
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -29,7 +31,7 @@ struct TranslateError { std::string msg; };
 [[noreturn]] void bad(const std::string& m) { throw TranslateError{m}; }
 
 enum Kind { NUM, ID, OP, END };
-struct Token { Kind kind; std::string text; };
+struct Token { Kind kind; std::string text; size_t pos = 0; };
 
 const char* const kOps3[] = {"<<=", ">>="};
 const char* const kOps2[] = {"->", "<<", ">>", "<=", ">=", "==", "!=", "&&", "||", "+=", "-=", "*=", "/=", "%=", "&=", "|=", "^=", "++", "--"};
@@ -58,7 +60,7 @@ std::vector<Token> tokenize(const std::string& src) {
             i += 2;
             while (i < n && isxdigit((unsigned char)text[i])) ++i;
             if (i < n && (text[i] == 'i' || text[i] == 'u')) ++i;
-            out.push_back({NUM, text.substr(start, i - start)});
+            out.push_back({NUM, text.substr(start, i - start), start});
             continue;
         }
         if (digit(i) || (text[i] == '.' && digit(i + 1))) {
@@ -70,20 +72,20 @@ std::vector<Token> tokenize(const std::string& src) {
                 if (digit(j)) { i = j; while (digit(i)) ++i; }
             }
             if (i < n && (text[i] == 'f' || text[i] == 'h' || text[i] == 'i' || text[i] == 'u')) ++i;
-            out.push_back({NUM, text.substr(start, i - start)});
+            out.push_back({NUM, text.substr(start, i - start), start});
             continue;
         }
         if (isalpha((unsigned char)text[i]) || text[i] == '_') {
             while (i < n && (isalnum((unsigned char)text[i]) || text[i] == '_')) ++i;
-            out.push_back({ID, text.substr(start, i - start)});
+            out.push_back({ID, text.substr(start, i - start), start});
             continue;
         }
         bool matched = false;
-        for (const char* op : kOps3) if (text.compare(i, 3, op) == 0) { out.push_back({OP, op}); i += 3; matched = true; break; }
+        for (const char* op : kOps3) if (text.compare(i, 3, op) == 0) { out.push_back({OP, op, i}); i += 3; matched = true; break; }
         if (matched) continue;
-        for (const char* op : kOps2) if (text.compare(i, 2, op) == 0) { out.push_back({OP, op}); i += 2; matched = true; break; }
+        for (const char* op : kOps2) if (text.compare(i, 2, op) == 0) { out.push_back({OP, op, i}); i += 2; matched = true; break; }
         if (matched) continue;
-        if (strchr(kOps1, text[i]) && text[i] != '\0') { out.push_back({OP, std::string(1, text[i])}); ++i; continue; }
+        if (strchr(kOps1, text[i]) && text[i] != '\0') { out.push_back({OP, std::string(1, text[i]), i}); ++i; continue; }
         bad("WGSL function string: cannot tokenize near '" + text.substr(i, 20) + "'");
     }
     return out;
@@ -175,7 +177,7 @@ struct Parser {
     std::map<std::string, std::string> builtins;
     std::vector<std::string> local_functions;
 
-    const Token& peek(size_t k = 0) const { static const Token end{END, ""}; return i + k < toks.size() ? toks[i + k] : end; }
+    const Token& peek(size_t k = 0) const { static const Token end{END, "", 0}; return i + k < toks.size() ? toks[i + k] : end; }
     Token take() { Token t = peek(); ++i; return t; }
     bool is(Kind k, const char* v, size_t ahead = 0) const { const Token& t = peek(ahead); return t.kind == k && t.text == v; }
     bool accept(const char* v) { if (peek().text == v && peek().kind != NUM && peek().kind != END) { ++i; return true; } return false; }
@@ -469,6 +471,226 @@ const char kPrelude[] =
     "    }\n"
     "};\n";
 
+
+// ---- planning of a whole payload (include/mcx.h: mcx_wgsl_plan) --------------------------------------------------------------
+// What the reference's Python half hands its native module is K strings; what they ARE is visible in their text. The three
+// recognitions below are the ones wgpu_montecarlo/_core.py made in Python until the binding's planning moved here
+// (tests/core_reference_planner.py keeps that Python as the test-suite's independent restatement).
+
+bool tok_is(const std::vector<Token>& t, size_t j, Kind k, const std::string& text) { return j < t.size() && t[j].kind == k && t[j].text == text; }
+
+// consumes `expected` (space-separated token texts) at position j; "%ID" matches any identifier, "%NUM" any number
+bool match_seq(const std::vector<Token>& t, size_t* j, const char* expected) {
+    size_t at = *j;
+    std::string word;
+    for (const char* c = expected;; ++c) {
+        if (*c == ' ' || *c == '\0') {
+            if (!word.empty()) {
+                if (at >= t.size()) return false;
+                if (word == "%ID") { if (t[at].kind != ID) return false; }
+                else if (word == "%NUM") { if (t[at].kind != NUM) return false; }
+                else if (t[at].text != word || t[at].kind == END) return false;
+                ++at;
+                word.clear();
+            }
+            if (*c == '\0') break;
+        } else word += *c;
+    }
+    *j = at;
+    return true;
+}
+
+std::string replace_all(std::string s, const std::string& from, const std::string& to) {
+    for (size_t at = 0; (at = s.find(from, at)) != std::string::npos; at += to.size()) s.replace(at, from.size(), to);
+    return s;
+}
+std::string strip(const std::string& s) {
+    size_t a = 0, b = s.size();
+    while (a < b && isspace((unsigned char)s[a])) ++a;
+    while (b > a && isspace((unsigned char)s[b - 1])) --b;
+    return s.substr(a, b - a);
+}
+
+struct Weighted { std::vector<std::string> f_texts; bool p_analytic = false, q_analytic = false; std::string p_text, q_text; };
+
+// Every string one of the reference's importance-sampling wrappers (python/wgpu_montecarlo/__init__.py:893-899, 968-974) around
+// the same p and q:  fn _is_wrapper_i(x: f32) -> f32 { let f_val = _is_f_orig_i(x); let p = <P>(x); let q = <Q>(x); return f_val * p / q; }
+// followed by the definitions of _is_pdf_p_i / _is_pdf_q_i (when analytic) and _is_f_orig_i (possibly with helpers).
+bool split_weighted(const char* const* functions, int k, Weighted* out) {
+    std::string p_seen, q_seen;
+    bool first = true;
+    for (int n = 0; n < k; ++n) {
+        const std::string text = functions[n] ? functions[n] : "";
+        std::vector<Token> t;
+        try { t = tokenize(text); } catch (const TranslateError&) { return false; }
+        if (t.size() < 4 || !tok_is(t, 0, ID, "fn") || t[1].kind != ID || t[1].text.rfind("_is_wrapper_", 0) != 0) return false;
+        const std::string i = t[1].text.substr(strlen("_is_wrapper_"));
+        if (i.empty()) return false;
+        for (char c : i) if (!isdigit((unsigned char)c)) return false;
+        size_t j = 2;
+        if (!match_seq(t, &j, "( x : f32 ) -> f32 { let f_val =") || !tok_is(t, j, ID, "_is_f_orig_" + i)) return false;
+        ++j;
+        if (!match_seq(t, &j, "( x ) ; let p =") || j >= t.size()) return false;
+        const std::string p_call = t[j++].text;
+        if (!match_seq(t, &j, "( x ) ; let q =") || j >= t.size()) return false;
+        const std::string q_call = t[j++].text;
+        if (!match_seq(t, &j, "( x ) ; return f_val * p / q ; }")) return false;
+        const bool p_tab = p_call == "pdf_target_from_table", q_tab = q_call == "pdf_proposal_from_table";
+        if (!p_tab && p_call != "_is_pdf_p_" + i) return false;
+        if (!q_tab && q_call != "_is_pdf_q_" + i) return false;
+        // the definitions that follow: each top-level `fn name(` starts one; helpers stay with the named one they follow
+        struct Part { std::string name; size_t begin; };
+        std::vector<Part> starts;
+        int depth = 0;
+        const size_t rest_tok = j;
+        for (size_t a = j; a < t.size(); ++a) {
+            if (t[a].kind == OP && t[a].text == "{") ++depth;
+            else if (t[a].kind == OP && t[a].text == "}") --depth;
+            else if (depth == 0 && t[a].kind == ID && t[a].text == "fn" && a + 2 < t.size() && t[a + 1].kind == ID && tok_is(t, a + 2, OP, "("))
+                starts.push_back({t[a + 1].text, t[a].pos});
+        }
+        if (starts.empty() || t[rest_tok].pos != starts[0].begin) return false;            // something before the first definition
+        std::string parts[3];                                                            // p, q, f
+        const std::string names[3] = {"_is_pdf_p_" + i, "_is_pdf_q_" + i, "_is_f_orig_" + i};
+        int current = -1;
+        for (size_t a = 0; a < starts.size(); ++a) {
+            const size_t end = a + 1 < starts.size() ? starts[a + 1].begin : text.size();
+            int which = -1;
+            for (int w = 0; w < 3; ++w) if (starts[a].name == names[w]) which = w;
+            if (which >= 0) current = which;
+            else if (current < 0) return false;
+            parts[current] += text.substr(starts[a].begin, end - starts[a].begin);
+        }
+        if (parts[2].empty() || parts[0].empty() == !p_tab || parts[1].empty() == !q_tab) return false;
+        const std::string p_norm = p_tab ? "" : strip(replace_all(parts[0], names[0], "_is_pdf_p"));
+        const std::string q_norm = q_tab ? "" : strip(replace_all(parts[1], names[1], "_is_pdf_q"));
+        if (first) { p_seen = p_norm; q_seen = q_norm; out->p_analytic = !p_tab; out->q_analytic = !q_tab; first = false; }
+        else if (p_norm != p_seen || q_norm != q_seen || out->p_analytic != !p_tab || out->q_analytic != !q_tab) return false;
+        out->f_texts.push_back(parts[2]);
+    }
+    out->p_text = p_seen;
+    out->q_text = q_seen;
+    return k > 0;
+}
+
+bool literal_value(const std::vector<Token>& t, size_t* j, double* v) {               // [-|+] NUM
+    double sign = 1.0;
+    if (tok_is(t, *j, OP, "-")) { sign = -1.0; ++*j; } else if (tok_is(t, *j, OP, "+")) ++*j;
+    if (*j >= t.size() || t[*j].kind != NUM) return false;
+    char* end = nullptr;
+    *v = sign * strtod(t[*j].text.c_str(), &end);
+    ++*j;
+    return true;
+}
+
+// Is `text` the closure Distribution.normal(mean, std) hands the transpiler (python/wgpu_montecarlo/__init__.py:343-347:
+// exp(-0.5 z z) / (sigma sqrt_2pi), z = (x - mean) / sigma) for exactly the parameters the call samples with?
+bool is_normal_pdf_text(const std::string& text, float mean, float std_) {
+    std::vector<Token> t;
+    try { t = tokenize(text); } catch (const TranslateError&) { return false; }
+    size_t j = 0;
+    if (!match_seq(t, &j, "fn %ID ( x : f32 ) -> f32 {")) return false;
+    double c_mean = 0, c_sigma = 0, c_s2pi = 0;
+    int seen = 0;
+    while (tok_is(t, j, ID, "const")) {
+        ++j;
+        if (j >= t.size() || t[j].kind != ID) return false;
+        const std::string name = t[j++].text;
+        double v = 0;
+        if (!match_seq(t, &j, ": f32 =") || !literal_value(t, &j, &v) || !match_seq(t, &j, ";")) return false;
+        if (name == "mean") { c_mean = v; seen |= 1; } else if (name == "sigma") { c_sigma = v; seen |= 2; }
+        else if (name == "sqrt_2pi") { c_s2pi = v; seen |= 4; } else return false;
+    }
+    if (seen != 7 || c_mean != (double)mean || c_sigma != (double)std_ || fabs(c_s2pi - 2.5066282746310002) >= 1e-12) return false;
+    return match_seq(t, &j, "var z = ( ( x - mean ) / sigma ) ; return ( exp ( ( ( ( - 0.5 ) * z ) * z ) ) / ( sigma * sqrt_2pi ) ) ; }") && j == t.size();
+}
+
+// exactly the transpiler's text for x, x**2, .., x**K (K >= 8): `return x;`, `return pow(x, k.0);`
+bool moment_family(const char* const* functions, int k) {
+    if (k < 8) return false;
+    for (int n = 0; n < k; ++n) {
+        std::vector<Token> t;
+        try { t = tokenize(functions[n] ? functions[n] : ""); } catch (const TranslateError&) { return false; }
+        size_t j = 0;
+        if (!match_seq(t, &j, "fn %ID ( x : f32 ) -> f32 { return")) return false;
+        if (n == 0) { if (!match_seq(t, &j, "x ; }") || j != t.size()) return false; continue; }
+        if (!match_seq(t, &j, "pow ( x , %NUM ) ; }") || j != t.size()) return false;
+        int e = 0;
+        if (!whole_exponent(number(t[j - 4].text), &e) || e != n + 1) return false;
+    }
+    return true;
+}
+
+std::string f32_literal(float v) {
+    char buf[48];
+    snprintf(buf, sizeof buf, "%.9g", (double)v);
+    std::string s = buf;
+    if (s.find_first_of(".eEn") == std::string::npos) s += ".0";                      // "2" -> "2.0" (inf / nan never reach here)
+    return s + "f";
+}
+
+// HIP text of the reference's analytic log-density of one distribution type, generate_log_pdf_code_for_dist
+// (src/shader_gen.rs:543-571): what its MH step evaluates when integrate_mcmc gets no table. The normal case is `pow(z, 2.0)` in
+// the reference's WGSL -- backend-defined for z < 0 -- and is emitted as the intended z * z.
+bool analytic_logpdf(const char* name, int dist_type, float p1, float p2, std::string* out) {
+    const std::string a = f32_literal(p1), b = f32_literal(p2);
+    std::string body;
+    if (dist_type == MCX_DIST_UNIFORM) body = "((" + a + " <= x) && (x < " + b + ")) ? -logf(" + b + " - " + a + ") : -100.0f";
+    else if (dist_type == MCX_DIST_NORMAL)
+        body = "-0.5f * (((x - " + a + ") / " + b + ") * ((x - " + a + ") / " + b + ")) - logf(" + b + " * 2.50662827463f)";
+    else if (dist_type == MCX_DIST_EXPONENTIAL) body = "(x >= 0.0f) ? logf(" + a + ") - " + a + " * x : -100.0f";
+    else return false;
+    *out = std::string("MCX_DEV float ") + name + "(float x) { return " + body + "; }";
+    return true;
+}
+
+int plan(const mcx_wgsl_program& g, mcx_module_desc* d, std::string* src) {
+    const bool literal = g.math == 0;
+    std::vector<std::string> parts = {kPrelude};
+    auto functions_as_given = [&] {
+        for (int i = 0; i < g.k; ++i) parts.push_back(translate(g.functions[i] ? g.functions[i] : "", i, "user_func_" + std::to_string(i), g.math));
+    };
+    d->kind = g.kind; d->k = g.k; d->dist_type = g.dist_type;
+    if (g.kind == MCX_KIND_INTEGRATE) {
+        Weighted w;
+        bool split = !literal && split_weighted(g.functions, g.k, &w);
+        if (split && (w.p_analytic == (g.have_target_table != 0) || w.q_analytic == (g.have_proposal_table != 0))) split = false;   // a wrapper reads a table the call did not bring (or the reverse): literal
+        if (split) {
+            // the reference's importance-sampling call: K integrands + ONE weight p / q per sample instead of K evaluations of its text
+            const bool q_sampler = w.q_analytic && g.dist_type == MCX_DIST_NORMAL && is_normal_pdf_text(w.q_text, g.param1, g.param2);
+            for (int i = 0; i < g.k; ++i) parts.push_back(translate(w.f_texts[i], i, "user_func_" + std::to_string(i), g.math));
+            if (w.p_analytic) parts.push_back(translate(w.p_text, g.k, "mcx_pdf_p", g.math));
+            if (w.q_analytic && !q_sampler) parts.push_back(translate(w.q_text, g.k + 1, "mcx_pdf_q", g.math));
+            d->weight = 1; d->p_table = w.p_analytic ? 0 : 1; d->q_table = w.q_analytic ? 0 : 1; d->q_sampler = q_sampler ? 1 : 0;
+        } else {
+            functions_as_given();
+            d->user_tables = (g.have_target_table ? 1 : 0) | (g.have_proposal_table ? 2 : 0);
+            d->moment_family = (!literal && d->user_tables == 0 && g.k <= 32 && moment_family(g.functions, g.k)) ? 1 : 0;
+        }
+    } else if (g.kind == MCX_KIND_MCMC) {
+        functions_as_given();
+        // the log-PDF tables are optional (src/lib.rs:296-304): without one, the MH step evaluates the analytic log-density of that
+        // distribution type (src/shader_gen.rs:327-339, 496-509). A normal proposal's log q is -z^2/2 + const of the deviate the
+        // sampler holds (not with math = precise): neither its table nor its text is used.
+        std::string text;
+        if (!g.have_target_table) {
+            if (!analytic_logpdf("mcx_logpdf_p", g.target_dist_type, g.target_param1, g.target_param2, &text))
+                return mcx::fail(MCX_E_RUNTIME, "Failed to create MCMC pipeline: a custom distribution needs its log-PDF table");
+            parts.push_back(text);
+            d->logpdf_analytic |= 1;
+        }
+        d->q_sampler = (!literal && g.dist_type == MCX_DIST_NORMAL) ? 1 : 0;
+        if (!d->q_sampler && !g.have_proposal_table) {
+            if (!analytic_logpdf("mcx_logpdf_q", g.dist_type, g.param1, g.param2, &text))
+                return mcx::fail(MCX_E_RUNTIME, "Failed to create MCMC pipeline: a custom distribution needs its log-PDF table");
+            parts.push_back(text);
+            d->logpdf_analytic |= 2;
+        }
+    } else return mcx::fail(MCX_E_INVALID, "mcx_wgsl_plan: kind must be MCX_KIND_INTEGRATE or MCX_KIND_MCMC");
+    *src = join(parts, "\n\n");
+    return MCX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -484,6 +706,25 @@ int mcx_wgsl_translate(const char* wgsl, int32_t slot, const char* entry_name, i
         if (!buf) return mcx::fail(MCX_E_RUNTIME, "out of memory");
         memcpy(buf, text.c_str(), text.size() + 1);
         *out_text = buf;
+        return MCX_OK;
+    } catch (const TranslateError& e) {
+        return mcx::fail(MCX_E_TRANSLATE, e.msg);
+    }
+}
+
+int mcx_wgsl_plan(const mcx_wgsl_program* prog, mcx_module_desc* desc_out, char** user_src_out) {
+    if (!prog || !desc_out || !user_src_out) return mcx::fail(MCX_E_INVALID, "mcx_wgsl_plan: null argument");
+    if (prog->struct_size != sizeof(mcx_wgsl_program)) return mcx::fail(MCX_E_INVALID, "mcx_wgsl_plan: program of another ABI version (mcx_wgsl_program_init)");
+    if (prog->k <= 0 || !prog->functions) return mcx::fail(MCX_E_INVALID, "At least one function is required");
+    if (prog->math < 0 || prog->math > 2) return mcx::fail(MCX_E_INVALID, "math must be one of ('precise', 'default', 'fast')");
+    mcx_module_desc_init(desc_out);
+    try {
+        std::string src;
+        if (int rc = plan(*prog, desc_out, &src)) return rc;
+        char* buf = (char*)malloc(src.size() + 1);
+        if (!buf) return mcx::fail(MCX_E_RUNTIME, "out of memory");
+        memcpy(buf, src.c_str(), src.size() + 1);
+        *user_src_out = buf;
         return MCX_OK;
     } catch (const TranslateError& e) {
         return mcx::fail(MCX_E_TRANSLATE, e.msg);

@@ -94,7 +94,7 @@ EXPORTED_SYMBOLS = [
     "mcx_comm_create", "mcx_comm_destroy", "mcx_comm_size", "mcx_integrate_comm", "mcx_mcmc_comm",
     "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct", "mcx_mcmc_block_hint", "mcx_cell_pads", "mcx_cell_pads_host", "mcx_default_launch_blocks", "mcx_engine_set_mcmc_segments",
     "mcx_abi_version", "mcx_module_key", "mcx_table_analyse", "mcx_table_facts_of", "mcx_engine_last_call", "mcx_module_block",
-    "mcx_module_desc_fit", "mcx_module_build_fitted", "mcx_module_desc_fit_host", "mcx_wgsl_translate", "mcx_wgsl_prelude",
+    "mcx_module_desc_fit", "mcx_module_build_fitted", "mcx_module_desc_fit_host", "mcx_wgsl_translate", "mcx_wgsl_prelude", "mcx_wgsl_plan",
 ]
 
 _lib = None
@@ -170,6 +170,7 @@ def load():
         L.mcx_module_precompile.argtypes = [C.c_char_p, C.POINTER(ModuleDesc), C.POINTER(C.c_int)]
         L.mcx_wgsl_translate.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(vp)]
         L.mcx_wgsl_prelude.restype = C.c_char_p
+        L.mcx_wgsl_plan.argtypes = [vp, C.POINTER(ModuleDesc), C.POINTER(vp)]
         L.mcx_module_desc_fit.argtypes = [C.POINTER(ModuleDesc), vp, vp, vp, C.c_float, C.c_float, C.POINTER(u32)]
         L.mcx_module_build_fitted.argtypes = [vp, C.c_char_p, C.POINTER(ModuleDesc), vp, vp, vp, u32, C.POINTER(vp)]
         L.mcx_module_desc_fit_host.argtypes = [C.POINTER(ModuleDesc), C.POINTER(TableFacts), C.POINTER(TableFacts), C.POINTER(C.c_float),
@@ -299,6 +300,41 @@ def make_desc(kind: int, k: int, dist_type: int, weight: bool = False, p_table: 
                       int(precise_sampler), int(block), int(tables_lds), int(rng), int(unit_params), int(second_moments),
                       int(walk), int(cell_tables), int(q_sampler), int(moment_family), int(user_tables), int(logpdf_analytic),
                       int(cdf_direct), int(cell_noclamp), int(cell_addr16))
+
+
+class WgslProgram(C.Structure):
+    """include/mcx.h: mcx_wgsl_program"""
+    _fields_ = [("struct_size", C.c_uint32), ("kind", C.c_int32), ("k", C.c_int32), ("functions", C.POINTER(C.c_char_p)),
+                ("dist_type", C.c_int32), ("param1", C.c_float), ("param2", C.c_float), ("math", C.c_int32),
+                ("have_target_table", C.c_int32), ("have_proposal_table", C.c_int32), ("target_dist_type", C.c_int32),
+                ("target_param1", C.c_float), ("target_param2", C.c_float)]
+
+
+def wgsl_plan(kind: int, functions, dist_type: int, p1: float, p2: float, math: str, have_target: bool, have_proposal: bool,
+              target_dist_type: int = 0, t1: float = 0.0, t2: float = 0.0):
+    """libmcx's planning of one payload of the reference's native module (include/mcx.h: mcx_wgsl_plan): K WGSL strings ->
+    (HIP text, desc with the structural fields set: weight / p_table / q_table / q_sampler, or user_tables / moment_family, or
+    logpdf_analytic). Needs no GPU. Raises TranspilerError for text outside the translator's subset."""
+    from .frontend import TranspilerError
+
+    codes = {"precise": 0, "default": 1, "fast": 2}
+    if math not in codes:
+        raise ValueError(f"math must be one of {tuple(codes)}")
+    if not all(isinstance(f, str) for f in functions):
+        raise TypeError("WGSL function strings expected")
+    texts = (C.c_char_p * max(len(functions), 1))(*[f.encode() for f in functions])
+    prog = WgslProgram(C.sizeof(WgslProgram), int(kind), len(functions), C.cast(texts, C.POINTER(C.c_char_p)), int(dist_type), float(p1),
+                       float(p2), codes[math], int(bool(have_target)), int(bool(have_proposal)), int(target_dist_type), float(t1), float(t2))
+    desc = ModuleDesc()
+    out = C.c_void_p()
+    rc = load().mcx_wgsl_plan(C.byref(prog), C.byref(desc), C.byref(out))
+    if rc == -5:
+        raise TranspilerError(last_error())
+    check(rc)
+    try:
+        return C.string_at(out).decode(), desc
+    finally:
+        load().mcx_free(out)
 
 
 def module_desc_fit(desc: ModuleDesc, cdf, t0, t1, p1: float, p2: float) -> int:
