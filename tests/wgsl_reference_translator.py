@@ -368,6 +368,8 @@ def translate(wgsl: str, slot: int, entry_name: str, math: str = "precise") -> s
         if parser.peek() == ("op", ";"):
             parser.take()
             continue
+        if len(pieces) >= len(names):                       # more top-level items than `fn name` pairs: the next one is not a function
+            raise TranspilerError("WGSL function string must start with 'fn'")
         name_for_emit = entry_name if first else parser.fn_name(names[len(pieces)])
         _, text = parser.function(name_for_emit)
         declarations.append(text.split("{", 1)[0].rstrip() + ";")
