@@ -327,6 +327,40 @@ static inline void mcx_wgsl_program_init(mcx_wgsl_program* g) {
 }
 int  mcx_wgsl_plan(const mcx_wgsl_program* prog, mcx_module_desc* desc_out, char** user_src_out);
 
+/* ------------------------------------------------------------------------------------------
+ * The reference's native module, call for call. `_core.MonteCarloIntegrator` (src/lib.rs:17-431) owns a ComputeEngine and has three
+ * methods that take WGSL strings, a distribution, float32 tables and sizes and return K float32 means. mcx_core is that object: an
+ * engine plus what the reference rebuilds on every call and libmcx keeps -- resident tables found again by content (the reference
+ * re-uploads them per call, src/engine.rs:235-295), planned + compiled modules found again by payload (it recompiles its shader per
+ * call, :325-331). A Rust / C host of src/lib.rs forwards its arguments unchanged. math: 0 literal / 1 default / 2 fast (mcx_wgsl_plan).
+ * Errors as the reference raises them: MCX_E_INVALID = ValueError ("At least one function is required", "n_steps must be positive"),
+ * MCX_E_RUNTIME / _COMPILE / _NODEVICE = RuntimeError, MCX_E_TRANSLATE = TranspilerError.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mcx_core mcx_core;
+int  mcx_core_create(int device, int32_t math, mcx_core** out);               /* MonteCarloIntegrator::new, src/lib.rs:24-31 */
+void mcx_core_destroy(mcx_core* c);
+mcx_engine* mcx_core_engine(mcx_core* c);                                     /* for mcx_engine_last_call etc.; owned by the core */
+/* The optional table arguments of the three methods (NULL / 0 = not given, as Python's None). */
+typedef struct mcx_core_tables {
+    uint32_t struct_size;                              /* mcx_core_tables_init() */
+    uint32_t n_cdf, n_target, n_proposal;
+    const float* x_table;   const float* cdf_table;    /* custom sampling / proposal distribution (src/lib.rs:71-77) */
+    const float* target_x;  const float* target_v;     /* integrate_is_tables: target PDF table; integrate_mcmc: target log-PDF table */
+    const float* proposal_x; const float* proposal_v;  /* likewise for the proposal */
+} mcx_core_tables;
+static inline void mcx_core_tables_init(mcx_core_tables* t) {
+    uint32_t i;
+    for (i = 0; i < sizeof(*t); ++i) ((unsigned char*)t)[i] = 0;
+    t->struct_size = (uint32_t)sizeof(*t);
+}
+/* integrate (src/lib.rs:47-141) and integrate_is_tables (:158-275; the PDF tables in `tables`): k WGSL strings -> values_out[k]. */
+int  mcx_core_integrate(mcx_core* c, const char* const* functions, int32_t k, int32_t dist_type, float param1, float param2,
+                        uint64_t n_samples, uint32_t seed, const mcx_core_tables* tables, int64_t target_threads, float* values_out);
+/* integrate_mcmc (src/lib.rs:296-431). A log-PDF table that is not given becomes the analytic log-density of that distribution type. */
+int  mcx_core_mcmc(mcx_core* c, const char* const* functions, int32_t k, int32_t proposal_dist_type, float param1, float param2,
+                   int32_t target_dist_type, float target_param1, float target_param2, uint32_t n_steps, uint32_t n_chains,
+                   uint32_t n_burnin, uint32_t seed, const mcx_core_tables* tables, int64_t target_threads, float* values_out);
+
 /* Where code objects are cached (default: <dir of libmcx.so>/jit_cache, override MCX_CACHE_DIR). The in-memory copy
  * is an LRU of MCX_CODE_CACHE_ENTRIES (default 256) code objects. */
 const char* mcx_cache_dir(void);

@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
     LOAD(mcx_rccl_library) LOAD(mcx_lds_table_budget) LOAD(mcx_module_static_lds) LOAD(mcx_engine_last_launch_count)
     LOAD(mcx_abi_version) LOAD(mcx_result_rows) LOAD(mcx_table_create) LOAD(mcx_table_release) LOAD(mcx_module_desc_fit)
     LOAD(mcx_module_build_fitted) LOAD(mcx_module_block) LOAD(mcx_wgsl_translate) LOAD(mcx_wgsl_prelude) LOAD(mcx_free)
-    LOAD(mcx_wgsl_plan)
+    LOAD(mcx_wgsl_plan) LOAD(mcx_core_create) LOAD(mcx_core_destroy) LOAD(mcx_core_integrate) LOAD(mcx_core_mcmc) LOAD(mcx_core_engine)
 
     printf("OK version %s\n", p_mcx_version());
     mcx_dispatch d;
@@ -200,6 +200,35 @@ int main(int argc, char** argv) {
         printf("OK planned from the reference's wrapper text: E_p[x]=%.6f E_p[x^2]=%.6f (hand-built module: %.6f %.6f)\n", ps2[0] / (double)pn,
                ps2[1] / (double)pn, ws[0] / (double)wn, ws[1] / (double)wn);
         if (pn != wn || fabs(ps2[0] - ws[0]) > 1e-6 * (double)wn || fabs(ps2[1] - ws[1]) > 1e-6 * (double)wn) return 1;
+        {   /* and as src/lib.rs would forward it: the reference's native object, call for call (strings + float32 tables in, K float32
+             * means out). The second call finds its tables by content and its module by payload. */
+            mcx_core* core = NULL;
+            if (p_mcx_core_create(0, 1, &core)) { fprintf(stderr, "core: %s\n", p_mcx_last_error()); return 1; }
+            mcx_core_tables ct;
+            mcx_core_tables_init(&ct);
+            ct.target_x = xs; ct.target_v = ps; ct.n_target = N;
+            float v1[2], v2[2];
+            if (p_mcx_core_integrate(core, payload, 2, MCX_DIST_NORMAL, 0.5f, 1.5f, 50000000ull, 7u, &ct, 0, v1) ||
+                p_mcx_core_integrate(core, payload, 2, MCX_DIST_NORMAL, 0.5f, 1.5f, 50000000ull, 7u, &ct, 0, v2)) {
+                fprintf(stderr, "core integrate: %s\n", p_mcx_last_error()); return 1;
+            }
+            if (v1[0] != v2[0] || v1[1] != v2[1] || v1[0] != (float)(ps2[0] / (double)pn) || v1[1] != (float)(ps2[1] / (double)pn)) {
+                fprintf(stderr, "core values %.9g %.9g vs %.9g %.9g\n", v1[0], v1[1], ps2[0] / (double)pn, ps2[1] / (double)pn); return 1;
+            }
+            /* integrate_mcmc with no tables at all: both log-densities analytic (src/shader_gen.rs:543-571), N(0.5, 1) target */
+            const char* fm[2] = {"fn user_func_0a(x: f32) -> f32 {\n    return x;\n}", "fn user_func_0b(x: f32) -> f32 {\n    return pow(x, 2.0);\n}"};
+            float vm[2];
+            if (p_mcx_core_mcmc(core, fm, 2, MCX_DIST_NORMAL, 0.0f, 2.0f, MCX_DIST_NORMAL, 0.5f, 1.0f, 2000u, 4096u, 200u, 42u, NULL, 0, vm)) {
+                fprintf(stderr, "core mcmc: %s\n", p_mcx_last_error()); return 1;
+            }
+            if (fabs(vm[0] - 0.5f) > 0.02f || fabs(vm[1] - 1.25f) > 0.05f) { fprintf(stderr, "core mcmc values %g %g\n", vm[0], vm[1]); return 1; }
+            if (p_mcx_core_integrate(core, payload, 0, MCX_DIST_NORMAL, 0.f, 1.f, 1000ull, 1u, NULL, 0, v1) != MCX_E_INVALID ||
+                !strstr(p_mcx_last_error(), "At least one function")) return 1;
+            if (p_mcx_core_mcmc(core, fm, 2, MCX_DIST_NORMAL, 0.0f, 2.0f, MCX_DIST_NORMAL, 0.5f, 1.0f, 0u, 4096u, 200u, 42u, NULL, 0, vm) != MCX_E_INVALID ||
+                !strstr(p_mcx_last_error(), "n_steps must be positive")) return 1;
+            printf("OK mcx_core: integrate_is_tables %.6f %.6f (twice, identical), integrate_mcmc %.4f %.4f\n", v2[0], v2[1], vm[0], vm[1]);
+            p_mcx_core_destroy(core);
+        }
         prog.math = 0;                                  /* literal: two functions that read the table themselves */
         char* literal = NULL;
         if (p_mcx_wgsl_plan(&prog, &pd, &literal) || pd.weight || pd.user_tables != 1 || !strstr(literal, "mcx_user_pdf_target(x)")) return 1;

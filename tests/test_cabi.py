@@ -17,7 +17,7 @@ HEADER = (ROOT / "include" / "mcx.h").read_text()
 def declared_symbols():
     names = set(re.findall(r"\b(mcx_[a-z0-9_]+)\s*\(", HEADER))
     inline = set(re.findall(r"static inline \w+ (mcx_[a-z0-9_]+)\s*\(", HEADER))      # the mcx_*_init helpers live in the header
-    assert inline == {"mcx_module_desc_init", "mcx_integrate_params_init", "mcx_mcmc_params_init", "mcx_wgsl_program_init"}
+    assert inline == {"mcx_module_desc_init", "mcx_integrate_params_init", "mcx_mcmc_params_init", "mcx_wgsl_program_init", "mcx_core_tables_init"}
     return sorted(names - inline)
 
 

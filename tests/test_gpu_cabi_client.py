@@ -39,4 +39,5 @@ def test_c_client_end_to_end(tmp_path, old_layout):
     res = subprocess.run([str(_build(tmp_path, old_layout)), str(LIB)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "OK integrate n_eff=100007936" in res.stdout and "OK errors" in res.stdout
-    assert old_layout or ("OK fitted importance sampling: cells 1" in res.stdout and "OK planned from the reference's wrapper text" in res.stdout), res.stdout
+    assert old_layout or ("OK fitted importance sampling: cells 1" in res.stdout and "OK planned from the reference's wrapper text" in res.stdout
+                          and "OK mcx_core: integrate_is_tables" in res.stdout), res.stdout

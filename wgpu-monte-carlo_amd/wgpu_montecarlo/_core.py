@@ -6,8 +6,10 @@ class `_core.MonteCarloIntegrator` (src/lib.rs:17-431; call sites python/wgpu_mo
 signatures, defaults, return type (float32[K]) and exception types -- so that the reference's own `__init__.py` and
 `transpiler.py` could run unchanged on an MI355X. The WGSL strings (the transpiler's output, user strings and the
 importance-sampling wrappers that call `pdf_target_from_table` / `pdf_proposal_from_table`) are planned and translated to
-HIP C++ inside libmcx (include/mcx.h: mcx_wgsl_plan, mcx_module_desc_fit) and fused into the same kernels; what is left here is
-the reference's argument conventions: its parameter dicts with their silent defaults, numpy tables, exception types, float32[K].
+HIP C++ inside libmcx and fused into the same kernels. libmcx has the reference's native object itself -- mcx_core_create /
+mcx_core_integrate / mcx_core_mcmc (include/mcx.h, csrc/mcx_core.cpp): an engine, its resident tables found again by content,
+its planned and compiled modules found again by payload --; what is left here is the reference's Python argument conventions:
+parameter dicts with their silent defaults, numpy tables, exception types, float32[K].
 
 Two ways of compiling what arrives, chosen by `math` (constructor keyword, or MCX_CORE_MATH):
   "precise"  literal: every string is one function of the kernel, evaluated as written -- the importance weight per
@@ -26,14 +28,19 @@ launches and the f64 reduction are libmcx's (include/mcx.h) -- a Rust or C host 
 """
 from __future__ import annotations
 
+import atexit
+import ctypes as C
 import os
+import threading
 from typing import Optional
 
 import numpy as np
 
 from . import runtime
 
-_PLANS: dict = {}            # one payload shape -> (HIP text, desc) as libmcx planned it; bounded, oldest out
+_CORES: dict = {}            # (device, math) -> mcx_core handle: every integrator of a process shares the engine, the resident tables and
+_CORES_LOCK = threading.Lock()   # the compiled modules of its device (the reference's convenience functions build an integrator per call)
+_MATH = {"precise": 0, "default": 1, "fast": 2}
 
 _DIST = {"uniform": runtime.DIST_UNIFORM, "normal": runtime.DIST_NORMAL, "exponential": runtime.DIST_EXPONENTIAL,
          "custom": runtime.DIST_CUSTOM}
@@ -59,10 +66,31 @@ def _params(dist_type: str, params: dict):
     return _DIST[dist_type], 0.0, 0.0
 
 
-def _f32(a) -> Optional[np.ndarray]:
-    """numpy inputs are copied as f32; a non-contiguous array silently becomes empty in the reference
-    (`as_slice().unwrap_or(&[])`, src/lib.rs:71-77) -- here it is simply made contiguous."""
-    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+class CoreTables(C.Structure):
+    """include/mcx.h: mcx_core_tables"""
+    _fields_ = [("struct_size", C.c_uint32), ("n_cdf", C.c_uint32), ("n_target", C.c_uint32), ("n_proposal", C.c_uint32),
+                ("x_table", C.POINTER(C.c_float)), ("cdf_table", C.POINTER(C.c_float)), ("target_x", C.POINTER(C.c_float)),
+                ("target_v", C.POINTER(C.c_float)), ("proposal_x", C.POINTER(C.c_float)), ("proposal_v", C.POINTER(C.c_float))]
+
+
+def _shared_core(device: int, math: str):
+    with _CORES_LOCK:
+        h = _CORES.get((device, math))
+        if h is None:
+            lib = runtime.load()
+            h = C.c_void_p()
+            runtime.check(lib.mcx_core_create(int(device), _MATH[math], C.byref(h)))    # RuntimeError("Failed to initialize GPU: ...")
+            _CORES[(device, math)] = h
+        return h
+
+
+@atexit.register
+def _destroy_cores():
+    with _CORES_LOCK:
+        lib = runtime.load() if _CORES else None
+        for h in _CORES.values():
+            lib.mcx_core_destroy(h)
+        _CORES.clear()
 
 
 class MonteCarloIntegrator:
@@ -73,113 +101,96 @@ class MonteCarloIntegrator:
         module docstring: "default" (the plan this package's API builds for the same call; also what MCX_CORE_MATH unset
         means), "fast", or "precise" (literal, ocml builtins). MCX_CORE_MATH sets it for callers that cannot pass it, such
         as the reference's unmodified __init__.py. BASELINE configs[1..3] through the binding, default / precise: 0.47 /
-        0.48, 0.79 / 4.6, 8.3 / 17.6 ms (profiles/r03_core_binding_payloads.txt)."""
-        self._engine = runtime.Engine.shared(device)           # RuntimeError("Failed to initialize GPU: ...")
+        0.48, 0.78 / 4.6, 8.2 / 17.6 ms (profiles/r03_core_binding_payloads.txt)."""
         self._math = math if math is not None else os.environ.get("MCX_CORE_MATH", "default")
-        if self._math not in ("precise", "default", "fast"):
+        if self._math not in _MATH:
             raise ValueError("math must be one of ('precise', 'default', 'fast')")
+        self._lib = runtime.load()
+        self._declare(self._lib)
+        self._core = _shared_core(int(device), self._math)
 
-    # ---- planning ---------------------------------------------------------------------------------
-    def _plan(self, kind, functions, code, p1, p2, have_target, have_proposal, t_code=0, t1=0.0, t2=0.0):
-        """(HIP text, desc) of one payload: libmcx's own planning (include/mcx.h: mcx_wgsl_plan), once per distinct call
-        shape -- the reference's Python half sends the same texts call after call."""
+    @staticmethod
+    def _declare(lib):
+        fp, u32 = C.POINTER(C.c_float), C.c_uint32
+        lib.mcx_core_create.argtypes = [C.c_int, C.c_int32, C.POINTER(C.c_void_p)]
+        lib.mcx_core_destroy.argtypes = [C.c_void_p]
+        lib.mcx_core_destroy.restype = None
+        lib.mcx_core_integrate.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_uint64, u32,
+                                           C.POINTER(CoreTables), C.c_int64, fp]
+        lib.mcx_core_mcmc.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_float,
+                                      C.c_float, u32, u32, u32, u32, C.POINTER(CoreTables), C.c_int64, fp]
+
+    # ---- argument conventions ---------------------------------------------------------------------
+    @staticmethod
+    def _strings(functions):
         if len(functions) == 0:
             raise ValueError("At least one function is required")          # src/lib.rs:61-65
-        try:
-            key = (kind, tuple(functions), code, p1, p2, self._math, have_target, have_proposal, t_code, t1, t2)
-            hit = _PLANS.get(key)
-        except TypeError:                                # an unhashable element: the planner refuses non-strings itself
-            key, hit = None, None
-        if hit is None:
-            hit = runtime.wgsl_plan(kind, functions, code, p1, p2, self._math, have_target, have_proposal, t_code, t1, t2)
-            if key is not None:
-                if len(_PLANS) >= 256:
-                    _PLANS.pop(next(iter(_PLANS)))
-                _PLANS[key] = hit
-        src, desc = hit
-        return src, runtime.ModuleDesc.from_buffer_copy(bytes(desc))        # the caller fits its own copy
+        if not all(isinstance(f, str) for f in functions):
+            raise TypeError("functions must be WGSL strings")
+        return (C.c_char_p * len(functions))(*[f.encode() for f in functions])
 
-    def _module(self, src: str, desc, p1: float, p2: float, cdf, t0=None, t1=None):
-        """math = "precise": the module as planned. Otherwise with libmcx's table decisions for the call (mcx_module_desc_fit:
-        cell form on strict grids, sentinel pads, LDS staging, bucket-direct sampling), held against the code object's real
-        static LDS exactly as api.py builds its plans."""
-        if self._math == "precise":
-            return self._engine.module(src, desc)
-        from . import api
+    @staticmethod
+    def _tables(x_table, cdf_table, target_x, target_v, proposal_x, proposal_v):
+        """numpy inputs are taken as contiguous f32 (a non-contiguous array silently becomes empty in the reference,
+        `as_slice().unwrap_or(&[])`, src/lib.rs:71-77 -- here it is simply made contiguous); a pair counts only if both halves came."""
+        fp = C.POINTER(C.c_float)
+        keep = []
 
-        pad_bytes = runtime.module_desc_fit(desc, cdf, t0, t1, p1, p2)
-        return api.build_module(self._engine, src, desc, cdf, t0, t1, extra_bytes=pad_bytes)
+        def pair(a, b):
+            if a is None or b is None:
+                return None, None, 0
+            a, b = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
+            if a.shape != b.shape or a.ndim != 1:
+                raise ValueError("table keys and values must be 1D arrays of the same length")
+            keep.extend((a, b))
+            return a.ctypes.data_as(fp), b.ctypes.data_as(fp), len(a)
 
-    def _cdf(self, dist_type: str, x_table, cdf_table):
-        if dist_type != "custom":
-            return None
-        x, c = _f32(x_table), _f32(cdf_table)
-        if x is None or c is None:
-            raise RuntimeError("Failed to setup integration: custom distribution requires x_table and cdf_table")
-        return self._engine.cached_table(runtime.TABLE_CDF, c, x)
+        x, c, n_cdf = pair(x_table, cdf_table)
+        tx, tv, n_t = pair(target_x, target_v)
+        px, pv, n_p = pair(proposal_x, proposal_v)
+        return CoreTables(C.sizeof(CoreTables), n_cdf, n_t, n_p, x, c, tx, tv, px, pv), keep
 
-    def _result(self, sums: np.ndarray, k: int, n_eff: int) -> np.ndarray:
-        with np.errstate(divide="ignore", invalid="ignore"):
-            return (sums[:k] / float(n_eff)).astype(np.float32)
+    def _check(self, rc: int) -> None:
+        if rc == -5:                                                       # MCX_E_TRANSLATE
+            from .frontend import TranspilerError
 
-    def _integrate(self, functions, dist_type, dist_params, n_samples, seed, x_table, cdf_table, target, proposal, target_threads):
-        """integrate / integrate_is_tables: `target` / `proposal` = (x, pdf) tables or None."""
-        if len(functions) == 0:
-            raise ValueError("At least one function is required")          # src/lib.rs:61-65
+            raise TranspilerError(runtime.last_error())
+        runtime.check(rc)                                                   # ValueError / RuntimeError as the reference raises them
+
+    def _integrate(self, functions, dist_type, dist_params, n_samples, seed, x_table, cdf_table, tx, tv, px, pv, target_threads):
+        texts = self._strings(functions)
         code, p1, p2 = _params(dist_type, dist_params)
-        cdf = self._cdf(dist_type, x_table, cdf_table)
-        p_tab = self._engine.cached_table(runtime.TABLE_PDF, _f32(target[0]), _f32(target[1])) if target is not None else None
-        q_tab = self._engine.cached_table(runtime.TABLE_PDF, _f32(proposal[0]), _f32(proposal[1])) if proposal is not None else None
-        src, desc = self._plan(runtime.KIND_INTEGRATE, functions, code, p1, p2, p_tab is not None, q_tab is not None)
-        mod = self._module(src, desc, p1, p2, cdf, p_tab, q_tab)
-        # the PDF tables are bound the same way whether the module weights with them (desc.weight) or its functions read them
-        # (desc.user_tables)
-        sums, n_eff = self._engine.integrate(mod, int(n_samples), int(seed), p1, p2, target_threads, cdf=cdf,
-                                             target_pdf=p_tab, proposal_pdf=q_tab)
-        return self._result(sums, len(functions), n_eff)
+        tables, keep = self._tables(x_table, cdf_table, tx, tv, px, pv)
+        out = np.zeros(len(functions), dtype=np.float32)
+        self._check(self._lib.mcx_core_integrate(self._core, texts, len(functions), code, p1, p2, int(n_samples), int(seed) & 0xFFFFFFFF,
+                                                 C.byref(tables), int(target_threads or 0), out.ctypes.data_as(C.POINTER(C.c_float))))
+        del keep
+        return out
 
     # ---- src/lib.rs:47-141 ------------------------------------------------------------------------
     def integrate(self, functions, dist_type, dist_params, n_samples, seed, x_table=None, cdf_table=None,
                   target_threads=None) -> np.ndarray:
-        return self._integrate(functions, dist_type, dist_params, n_samples, seed, x_table, cdf_table, None, None, target_threads)
+        return self._integrate(functions, dist_type, dist_params, n_samples, seed, x_table, cdf_table, None, None, None, None, target_threads)
 
     # ---- src/lib.rs:158-275 -----------------------------------------------------------------------
     def integrate_is_tables(self, functions, dist_type, dist_params, n_samples, seed, x_table=None, cdf_table=None,
                             target_x_table=None, target_pdf_table=None, proposal_x_table=None,
                             proposal_pdf_table=None, target_threads=None) -> np.ndarray:
-        target = (target_x_table, target_pdf_table) if target_x_table is not None and target_pdf_table is not None else None
-        proposal = (proposal_x_table, proposal_pdf_table) if proposal_x_table is not None and proposal_pdf_table is not None else None
-        return self._integrate(functions, dist_type, dist_params, n_samples, seed, x_table, cdf_table, target, proposal, target_threads)
+        return self._integrate(functions, dist_type, dist_params, n_samples, seed, x_table, cdf_table, target_x_table, target_pdf_table,
+                               proposal_x_table, proposal_pdf_table, target_threads)
 
     # ---- src/lib.rs:296-431 -----------------------------------------------------------------------
     def integrate_mcmc(self, functions, proposal_dist_type, proposal_dist_params, target_dist_type, target_dist_params,
                        n_steps, n_chains, n_burnin, seed, x_table=None, cdf_table=None, target_x_table=None,
                        target_log_pdf_table=None, proposal_x_table=None, proposal_log_pdf_table=None,
                        target_threads=None) -> np.ndarray:
-        if len(functions) == 0:
-            raise ValueError("At least one function is required")
-        if int(n_steps) == 0:
-            raise ValueError("n_steps must be positive")                    # src/lib.rs:332-336
-        if int(n_chains) == 0:
-            raise ValueError("n_chains must be positive")                   # src/lib.rs:338-342
+        texts = self._strings(functions)
         code, p1, p2 = _params(proposal_dist_type, proposal_dist_params)
         t_code, t1, t2 = _params(target_dist_type, target_dist_params)
-        cdf = self._cdf(proposal_dist_type, x_table, cdf_table)
-        have_t = target_x_table is not None and target_log_pdf_table is not None
-        have_q = proposal_x_table is not None and proposal_log_pdf_table is not None
-        # the log-PDF tables are optional (src/lib.rs:296-304): the plan says which of them the module reads (a missing one becomes
-        # the analytic log-density of that distribution type; a normal proposal's log q comes from its own deviate unless math is
-        # "precise")
-        src, desc = self._plan(runtime.KIND_MCMC, functions, code, p1, p2, have_t, have_q, t_code, t1, t2)
-        t = self._engine.cached_table(runtime.TABLE_LOGPDF, _f32(target_x_table), _f32(target_log_pdf_table)) if have_t else None
-        q = None
-        if have_q and not desc.q_sampler:
-            q = self._engine.cached_table(runtime.TABLE_LOGPDF, _f32(proposal_x_table), _f32(proposal_log_pdf_table))
-        if self._math != "precise":
-            # the workgroup size a small chain count wants (one chain per thread)
-            hint = runtime.mcmc_block_hint(runtime.mcmc_dispatch_config(int(n_chains), target_threads).total_threads)
-            desc.block = 0 if hint >= 1024 else hint
-        mod = self._module(src, desc, p1, p2, cdf, t, q)
-        sums, n_eff = self._engine.mcmc(mod, int(n_steps), int(n_chains), int(n_burnin), int(seed), p1, p2, t, q,
-                                        target_threads=target_threads, cdf=cdf)
-        return self._result(sums, len(functions), n_eff)
+        tables, keep = self._tables(x_table, cdf_table, target_x_table, target_log_pdf_table, proposal_x_table, proposal_log_pdf_table)
+        out = np.zeros(len(functions), dtype=np.float32)
+        self._check(self._lib.mcx_core_mcmc(self._core, texts, len(functions), code, p1, p2, t_code, t1, t2, int(n_steps), int(n_chains),
+                                            int(n_burnin), int(seed) & 0xFFFFFFFF, C.byref(tables), int(target_threads or 0),
+                                            out.ctypes.data_as(C.POINTER(C.c_float))))
+        del keep
+        return out

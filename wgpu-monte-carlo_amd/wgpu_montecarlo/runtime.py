@@ -95,6 +95,7 @@ EXPORTED_SYMBOLS = [
     "mcx_selftest_streams", "mcx_set_max_launch_units", "mcx_table_has_direct", "mcx_mcmc_block_hint", "mcx_cell_pads", "mcx_cell_pads_host", "mcx_default_launch_blocks", "mcx_engine_set_mcmc_segments",
     "mcx_abi_version", "mcx_module_key", "mcx_table_analyse", "mcx_table_facts_of", "mcx_engine_last_call", "mcx_module_block",
     "mcx_module_desc_fit", "mcx_module_build_fitted", "mcx_module_desc_fit_host", "mcx_wgsl_translate", "mcx_wgsl_prelude", "mcx_wgsl_plan",
+    "mcx_core_create", "mcx_core_destroy", "mcx_core_engine", "mcx_core_integrate", "mcx_core_mcmc",
 ]
 
 _lib = None
