@@ -91,6 +91,24 @@ def test_text_outside_the_subset_is_refused_alike(text):
     assert str(got.value) == str(want.value)
 
 
+def test_nesting_is_bounded():
+    """Text from a caller cannot run the recursive descent off the stack."""
+    ok = "fn f(x: f32) -> f32 { return " + "(" * 150 + "x" + ")" * 150 + "; }"
+    limit = sys.getrecursionlimit()
+    sys.setrecursionlimit(20000)                    # the Python restatement spends a dozen frames per parenthesis
+    try:
+        assert wgsl_to_hip.translate(ok, 0, "user_func_0") == ref.translate(ok, 0, "user_func_0")
+        with pytest.raises(TranspilerError, match="nesting deeper than 200"):
+            ref.translate("fn f(x: f32) -> f32 { return " + "(" * 300 + "x" + ")" * 300 + "; }", 0, "user_func_0")
+    finally:
+        sys.setrecursionlimit(limit)
+    for deep in ("fn f(x: f32) -> f32 { return " + "(" * 100000 + "x" + ")" * 100000 + "; }",
+                 "fn f(x: f32) -> f32 { return " + "!" * 100000 + "x; }",
+                 "fn f(x: f32) -> f32 " + "{" * 100000 + "}" * 100000):
+        with pytest.raises(TranspilerError, match="nesting deeper than 200"):
+            wgsl_to_hip.translate(deep, 0, "user_func_0")
+
+
 def test_tokenizer_error_and_argument_checks():
     with pytest.raises(TranspilerError, match="cannot tokenize near"):
         wgsl_to_hip.translate("fn f(x: f32) -> f32 { return x $ 2.0; }", 0, "user_func_0")

@@ -156,7 +156,20 @@ class _Parser:
             left = f"mcx_mod({left}, {right})" if op == "%" else f"({left} {op} {right})"
         return left
 
+    def _nest(self):
+        """The descent is bounded: parentheses, unary operators and blocks nest at most 200 deep."""
+        self.nesting = getattr(self, "nesting", 0) + 1
+        if self.nesting > 200:
+            raise TranspilerError("WGSL function string: nesting deeper than 200 levels")
+
     def unary(self) -> str:
+        self._nest()
+        try:
+            return self._unary()
+        finally:
+            self.nesting -= 1
+
+    def _unary(self) -> str:
         if self.peek() == ("op", "-"):
             self.take()
             return f"(-{self.unary()})"
@@ -222,6 +235,13 @@ class _Parser:
 
     # ---- statements ----
     def block(self, indent: int) -> List[str]:
+        self._nest()
+        try:
+            return self._block(indent)
+        finally:
+            self.nesting -= 1
+
+    def _block(self, indent: int) -> List[str]:
         self.expect("{")
         out: List[str] = []
         while not self.accept("}"):

@@ -194,6 +194,14 @@ struct Parser {
     static std::string var_name(const std::string& name) { return name.rfind("mcx_", 0) == 0 ? name + "_v" : name; }
     bool is_local(const std::string& name) const { for (auto& f : local_functions) if (f == name) return true; return false; }
 
+    // text from a caller: the recursive descent is bounded (parentheses, unary operators and blocks nest at most kMaxNesting deep)
+    int nesting = 0;
+    struct Nest {
+        int& n;
+        explicit Nest(int& depth) : n(depth) { if (++n > 200) bad("WGSL function string: nesting deeper than 200 levels"); }
+        ~Nest() { --n; }
+    };
+
     std::string expression(size_t level = 0) {
         if (level == kLevels.size()) return unary();
         std::string left = expression(level + 1);
@@ -209,6 +217,7 @@ struct Parser {
         return left;
     }
     std::string unary() {
+        Nest guard(nesting);
         for (const char* op : {"-", "!", "~"})
             if (is(OP, op)) { take(); return std::string("(") + op + unary() + ")"; }
         return primary();
@@ -267,6 +276,7 @@ struct Parser {
 
     static std::string pad(int indent) { return std::string(4 * (size_t)indent, ' '); }
     std::vector<std::string> block(int indent) {
+        Nest guard(nesting);
         expect("{");
         std::vector<std::string> out;
         while (!accept("}")) {
