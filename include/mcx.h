@@ -57,9 +57,10 @@ const char* mcx_last_error(void);
  *   - a caller built against a newer, longer layout than this library is refused with MCX_E_INVALID;
  *   - struct_size = 0 (a struct that was never initialised) is refused with MCX_E_INVALID.
  * MCX_ABI_VERSION counts layouts: 1 = round 1 (module desc up to `unit_params`), 2 = round 2 (up to `cell_addr16`,
- * unversioned), 3 = this one (struct_size first).
+ * unversioned), 3 = struct_size first, 4 = the versioned structs of 3 unchanged, plus mcx_wgsl_program / mcx_core_tables and the
+ * entry points that take them (mcx_wgsl_*, mcx_module_desc_fit*, mcx_core_*): a host checks >= 4 before it looks them up.
  * ------------------------------------------------------------------------------------------ */
-#define MCX_ABI_VERSION 3
+#define MCX_ABI_VERSION 4
 uint32_t mcx_abi_version(void);        /* MCX_ABI_VERSION the library was built with */
 
 /* ------------------------------------------------------------------------------------------

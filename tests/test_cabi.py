@@ -238,7 +238,7 @@ def test_versioned_structs_accept_older_layouts_and_refuse_newer_ones():
     """include/mcx.h "ABI versioning": struct_size first; shorter = an older caller (missing fields read as 0), longer =
     a caller built against a newer header (refused), 0 = never initialised (refused)."""
     lib = rt.load()
-    assert int(lib.mcx_abi_version()) == rt.ABI_VERSION == 3
+    assert int(lib.mcx_abi_version()) == rt.ABI_VERSION == 4
     desc = rt.make_desc(rt.KIND_MCMC, 2, rt.DIST_NORMAL, second_moments=True, walk=rt.WALK_ADAPTIVE)
     assert desc.struct_size == C.sizeof(rt.ModuleDesc)
     assert rt.result_rows(desc) == 3 * 2 + 1 + 1

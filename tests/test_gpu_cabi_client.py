@@ -25,7 +25,7 @@ def test_c_client_planning_without_gpu(tmp_path, old_layout):
     res = subprocess.run([str(_build(tmp_path, old_layout)), str(LIB)], capture_output=True, text=True, timeout=120)
     assert res.returncode in (0, 3), res.stdout + res.stderr
     assert "OK planning T=65536 L=16" in res.stdout and "OK wgsl translated" in res.stdout
-    m = re.search(r"OK abi version 3, desc of (\d+) bytes \(library: (\d+)\)", res.stdout)
+    m = re.search(r"OK abi version 4, desc of (\d+) bytes \(library: (\d+)\)", res.stdout)
     assert m, res.stdout
     mine, libs = int(m.group(1)), int(m.group(2))
     assert (mine == 52 and libs > mine) if old_layout else (mine == libs), res.stdout

@@ -80,7 +80,7 @@ class CallInfo(C.Structure):
 
 _SZ_INTEGRATE, _SZ_MCMC = C.sizeof(IntegrateParams), C.sizeof(McmcParams)
 SEGMENTS_AUTO = 0xFFFFFFFF
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/mcx.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
