@@ -31,10 +31,20 @@ def test_repeat_calls_hit_and_changed_captures_miss(monkeypatch):
     assert b is not a and "5.0" in b.module.user_src             # a global the function reads changed
     monkeypatch.setitem(globals(), "SCALE", 2.0)
     assert _plan(mc, family(3), dist) is a
-    # another distribution object with the same parameters is another key (identity), and compiles to the same module
-    c = _plan(mc, family(3), Distribution.normal(0.0, 1.0))
-    assert c is not a and c.module.key == a.module.key
+    # another distribution object with the same parameters is the same key (by value: the reference's examples write
+    # `Distribution.normal(0, 1)` inline in every call); other parameters are another plan
+    assert _plan(mc, family(3), Distribution.normal(0.0, 1.0)) is a
+    assert _plan(mc, family(3), Distribution.uniform(0.0, 1.0)) is not a
     assert _plan(mc, family(3), Distribution.normal(0.5, 1.0)).desc.unit_params == 0
+    n_plans = len(mc._engine._plans)
+    for _ in range(5):
+        _plan(mc, family(3), Distribution.normal(0.0, 1.0))
+        _plan(mc, family(3), Distribution.exponential(2.0))
+    assert len(mc._engine._plans) == n_plans + 1                  # one new entry (exponential(2)), not ten
+    # table-backed distributions are keyed by their arrays: two constructions are two plans, the same object is one
+    beta = Distribution.beta(2.0, 5.0)
+    assert _plan(mc, family(3), beta) is _plan(mc, family(3), beta)
+    assert _plan(mc, family(3), Distribution.beta(2.0, 5.0)) is not _plan(mc, family(3), beta)
     # the integrator's mode is part of the key; plans are shared per engine, not per integrator
     other = MonteCarloIntegrator.planner(rng="philox")
     other._engine = mc._engine

@@ -70,13 +70,19 @@ def _function_key(fn):
 
 
 def _distribution_key(d: Distribution):
-    """Identity of a Distribution for the plan cache. The cache entry keeps the object alive, so id() cannot be reused
-    while the entry exists; parameters and the identities of its closure / tables are part of the key, so replacing any
-    of them is seen. (Writing into a table array IN PLACE after it has been used is not: tables are treated as
-    immutable once a call has seen them -- build a new Distribution instead.)"""
+    """Identity of a Distribution for the plan cache: its type, its parameters, the fingerprint of its density closure (code
+    object + every captured value, as for integrands) and the identities of its table arrays -- by value where a value exists, so
+    that `Distribution.normal(0, 1)` written inline in every call (the reference's examples and benchmark do) finds the plan of the
+    previous call instead of building and caching a new one each time. A density that cannot be fingerprinted falls back to the
+    object's identity (the cache entry keeps the object alive, so an id() cannot be reused while the entry exists). Writing into
+    a table array IN PLACE after it has been used is not seen: tables are treated as immutable once a call has seen them."""
     p = d.params
-    return (id(d), d.dist_type, tuple(p.items()) if p else None, id(d._pdf_func), id(d._x_table), id(d._cdf_table),
-            id(d._pdf_table))
+    try:
+        density = frontend.fingerprint(d._pdf_func)
+        hash(density)
+    except (TypeError, AttributeError, ValueError, TranspilerError):
+        density = (id(d), id(d._pdf_func))
+    return (d.dist_type, tuple(p.items()) if p else None, density, id(d._x_table), id(d._cdf_table), id(d._pdf_table))
 
 
 _PLAN_CACHE_ENTRIES = 128
