@@ -236,3 +236,32 @@ def test_the_binding_takes_a_math_mode(monkeypatch):
     assert np.allclose(_core.MonteCarloIntegrator(math="fast").integrate(*args), precise, rtol=0, atol=5e-6)
     with pytest.raises(ValueError):
         _core.MonteCarloIntegrator(math="quick")
+
+
+def test_the_core_objects_caches_are_bounded():
+    """mcx_core keeps resident tables (64, by content) and compiled modules (128, by payload): more distinct ones than that are
+    evicted and rebuilt, results stay right, and device memory does not grow with the number of distinct calls."""
+    import torch
+
+    from wgpu_montecarlo import _core
+
+    core = _core.MonteCarloIntegrator()
+    free0 = None
+    for lap in range(2):
+        for j in range(70):                                  # 70 different target tables through 64 slots
+            xs = np.linspace(-6.0, 6.0, 300 + j).astype(np.float32)
+            ps = (np.exp(-0.5 * xs.astype(np.float64) ** 2) / np.sqrt(2 * np.pi)).astype(np.float32)
+            text = (f"\nfn _is_wrapper_0(x: f32) -> f32 {{\n    let f_val = _is_f_orig_0(x);\n    let p = pdf_target_from_table(x);\n"
+                    f"    let q = _is_pdf_q_0(x);\n    return f_val * p / q;\n}}\n\n\nfn _is_pdf_q_0(x: f32) -> f32 {{\n    const mean: f32 = 0.0;\n"
+                    f"    const sigma: f32 = 2.0;\n    const sqrt_2pi: f32 = 2.5066282746310002;\n    var z = ((x - mean) / sigma);\n"
+                    f"    return (exp((((-0.5) * z) * z)) / (sigma * sqrt_2pi));\n}}\nfn _is_f_orig_0(x: f32) -> f32 {{\n    return pow(x, 2.0);\n}}\n")
+            got = core.integrate_is_tables([text], "normal", {"mean": 0.0, "std": 2.0}, 200_000, 3, None, None, xs, ps, None, None, None)
+            assert abs(got[0] - 1.0) < 0.05, (lap, j, got)
+        for j in range(140):                                 # 140 different payloads through 128 slots
+            got = core.integrate([f"fn f(x: f32) -> f32 {{ return x * {j}.0 + 1.0; }}"], "uniform", {"min": 0.0, "max": 1.0}, 100_000, 5)
+            assert abs(got[0] - (0.5 * j + 1.0)) < 0.01 * (j + 1), (lap, j, got)
+        torch.cuda.synchronize()
+        free = torch.cuda.mem_get_info(0)[0]
+        if free0 is None:
+            free0 = free
+    assert free0 - free < 64 * 2**20, (free0, free)          # the second lap rebuilt what the first evicted: no growth
