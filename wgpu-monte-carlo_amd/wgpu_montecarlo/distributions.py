@@ -113,6 +113,7 @@ def _compute_cdf_table(pdf: Callable, x_min: float, x_max: float, n_points: int 
 
 _CDF_TABLES: dict = {}        # (density key, support, size) -> (x f32, cdf f32), read-only; bounded, oldest out
 _SUPPORTS: dict = {}          # density key -> (x_min, x_max) found by _find_support
+_PDF_TABLES: dict = {}        # (density key, x grid bytes) -> pdf f32 on that grid, read-only
 
 
 _PLAIN = (int, float, bool, str, complex, type(None), np.generic, types.ModuleType, types.BuiltinFunctionType, np.ufunc)
@@ -304,7 +305,22 @@ class Distribution:
         if self._x_table is None:
             x_min, x_max = self.params.get("support", (-5.0, 5.0))
             self._x_table = np.linspace(x_min, x_max, self.params.get("table_size", 2048), dtype=np.float32)
-        self._pdf_table = np.array([self._pdf_func(float(x)) for x in self._x_table], dtype=np.float32)
+        # the 2048 density evaluations, once per distinct density and grid (an inline Distribution.normal(0, 2) as the proposal of
+        # every integrate_mcmc call is a new object each time)
+        try:
+            key = _density_key(self._pdf_func)
+            key = None if key is None else (key, self._x_table.tobytes())
+            hit = _PDF_TABLES.get(key) if key is not None else None
+        except (TypeError, ValueError):
+            key, hit = None, None
+        if hit is None:
+            hit = np.array([self._pdf_func(float(x)) for x in self._x_table], dtype=np.float32)
+            if key is not None:
+                hit.setflags(write=False)
+                if len(_PDF_TABLES) >= 64:
+                    _PDF_TABLES.pop(next(iter(_PDF_TABLES)))
+                _PDF_TABLES[key] = hit
+        self._pdf_table = hit
         return self._x_table, self._pdf_table
 
     def get_log_pdf_table(self, min_log_value: float = -100.0) -> Tuple[np.ndarray, np.ndarray]:
