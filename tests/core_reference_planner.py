@@ -18,7 +18,7 @@ _WRAPPER = re.compile(
     r"let\s+p\s*=\s*(pdf_target_from_table|_is_pdf_p_\1)\s*\(\s*x\s*\)\s*;\s*"
     r"let\s+q\s*=\s*(pdf_proposal_from_table|_is_pdf_q_\1)\s*\(\s*x\s*\)\s*;\s*"
     r"return\s+f_val\s*\*\s*p\s*/\s*q\s*;\s*\}", re.S)
-_FN_START = re.compile(r"(?m)^[ \t]*fn\s+([A-Za-z_][A-Za-z_0-9]*)\s*\(")
+_FN_START = re.compile(r"\bfn\s+([A-Za-z_][A-Za-z_0-9]*)\s*\(")
 
 
 def _split_weighted(functions):
@@ -31,7 +31,8 @@ def _split_weighted(functions):
             return None
         i, p_call, q_call = m.group(1), m.group(2), m.group(3)
         rest = text[m.end():]
-        starts = [(g.start(), g.group(1)) for g in _FN_START.finditer(rest)]
+        # a definition starts at a `fn name(` outside every brace (as libmcx's planner walks the tokens)
+        starts = [(g.start(), g.group(1)) for g in _FN_START.finditer(rest) if rest[:g.start()].count("{") == rest[:g.start()].count("}")]
         parts = {}                                  # the three named definitions; helpers stay with the one they follow
         order = []
         for j, (pos, name) in enumerate(starts):
@@ -80,6 +81,8 @@ def _is_normal_pdf_text(text: Optional[str], mean: float, std: float) -> bool:
     function of the deviate the sampler already holds (desc.q_sampler), as in api.py."""
     if text is None:
         return False
+    if not re.match(r"^\s*fn\s+\w+\s*\(\s*x\s*:\s*f32\s*\)\s*->\s*f32\s*\{", text) or not text.rstrip().endswith("}"):
+        return False                                     # the whole definition in the generator's format, not only its body
     consts = dict(re.findall(r"const\s+(\w+)\s*:\s*f32\s*=\s*([-+0-9.eE]+)\s*;", text))
     body = re.sub(r"\s+", "", text)
     try:

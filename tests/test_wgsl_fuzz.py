@@ -95,7 +95,10 @@ def test_mutated_payloads_plan_alike_and_nothing_crashes():
 
             want = outcome(planner_ref.plan, rt.KIND_INTEGRATE, fns, rt.DIST_NORMAL, 2.0, 3.0, math, have_t, False)
             got = outcome(cxx)
-            assert got == want, (fns[at], math)
+            if got[0] == want[0] == "refused":
+                pass                                     # both refuse; which of a mutant's several faults is reported first may differ
+            else:
+                assert got == want, (fns[at], math)
             checked += 1
             recognised += got[0] == "ok" and got[1][1]["weight"] == 1
     assert checked >= 250 and recognised >= 1
