@@ -14,6 +14,7 @@ Checked against tables captured from the reference in tests/golden/ (tools/make_
 from __future__ import annotations
 
 import math
+import threading
 import types
 from enum import Enum, auto
 from typing import Callable, Optional, Sequence, Tuple, Union
@@ -114,6 +115,14 @@ def _compute_cdf_table(pdf: Callable, x_min: float, x_max: float, n_points: int 
 _CDF_TABLES: dict = {}        # (density key, support, size) -> (x f32, cdf f32), read-only; bounded, oldest out
 _SUPPORTS: dict = {}          # density key -> (x_min, x_max) found by _find_support
 _PDF_TABLES: dict = {}        # (density key, x grid bytes) -> pdf f32 on that grid, read-only
+_TABLE_LOCK = threading.Lock()    # updates of the three (lookups are lock-free)
+
+
+def _remember(cache: dict, key, value, limit: int = 64) -> None:
+    with _TABLE_LOCK:
+        while len(cache) >= limit:
+            cache.pop(next(iter(cache)))             # oldest entry (dicts keep insertion order)
+        cache[key] = value
 
 
 _PLAIN = (int, float, bool, str, complex, type(None), np.generic, types.ModuleType, types.BuiltinFunctionType, np.ufunc)
@@ -154,9 +163,7 @@ def _cached_cdf_table(pdf: Callable, x_min: float, x_max: float, n_points: int):
         if key is not None:
             for a in hit:
                 a.setflags(write=False)
-            if len(_CDF_TABLES) >= 64:
-                _CDF_TABLES.pop(next(iter(_CDF_TABLES)))
-            _CDF_TABLES[key] = hit
+            _remember(_CDF_TABLES, key, hit)
     return hit
 
 
@@ -244,9 +251,7 @@ class Distribution:
             if found is None:
                 found = _find_support(pdf_func)
                 if skey is not None:
-                    if len(_SUPPORTS) >= 64:
-                        _SUPPORTS.pop(next(iter(_SUPPORTS)))
-                    _SUPPORTS[skey] = found
+                    _remember(_SUPPORTS, skey, found)
             x_min, x_max = found
         xs, cdf = _cached_cdf_table(pdf_func, x_min, x_max, table_size)
         return Distribution(DistributionType.CUSTOM, {"table_size": len(xs), "support": (x_min, x_max)},
@@ -317,9 +322,7 @@ class Distribution:
             hit = np.array([self._pdf_func(float(x)) for x in self._x_table], dtype=np.float32)
             if key is not None:
                 hit.setflags(write=False)
-                if len(_PDF_TABLES) >= 64:
-                    _PDF_TABLES.pop(next(iter(_PDF_TABLES)))
-                _PDF_TABLES[key] = hit
+                _remember(_PDF_TABLES, key, hit)
         self._pdf_table = hit
         return self._x_table, self._pdf_table
 
