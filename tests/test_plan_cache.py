@@ -41,10 +41,16 @@ def test_repeat_calls_hit_and_changed_captures_miss(monkeypatch):
         _plan(mc, family(3), Distribution.normal(0.0, 1.0))
         _plan(mc, family(3), Distribution.exponential(2.0))
     assert len(mc._engine._plans) == n_plans + 1                  # one new entry (exponential(2)), not ten
-    # table-backed distributions are keyed by their arrays: two constructions are two plans, the same object is one
+    # table-backed distributions are keyed by their density and their arrays; the tables of a repeated inline density are built
+    # once (distributions._cached_cdf_table), so a second Distribution.beta(2, 5) is the same plan too
     beta = Distribution.beta(2.0, 5.0)
     assert _plan(mc, family(3), beta) is _plan(mc, family(3), beta)
-    assert _plan(mc, family(3), Distribution.beta(2.0, 5.0)) is not _plan(mc, family(3), beta)
+    assert _plan(mc, family(3), Distribution.beta(2.0, 5.0)) is _plan(mc, family(3), beta)
+    assert _plan(mc, family(3), Distribution.beta(2.0, 5.5)) is not _plan(mc, family(3), beta)
+    # a density that captures arrays has no value: keyed by the object
+    xs = np.linspace(-3, 3, 200)
+    t1, t2 = Distribution.from_pdf_table(xs, np.exp(-xs * xs)), Distribution.from_pdf_table(xs, np.exp(-xs * xs))
+    assert _plan(mc, family(3), t1) is _plan(mc, family(3), t1) and _plan(mc, family(3), t2) is not _plan(mc, family(3), t1)
     # the integrator's mode is part of the key; plans are shared per engine, not per integrator
     other = MonteCarloIntegrator.planner(rng="philox")
     other._engine = mc._engine

@@ -21,7 +21,7 @@ from typing import Callable, List, Optional, Sequence, Union
 import numpy as np
 
 from . import distributed, emit_hip, frontend, runtime, wgsl_to_hip
-from .distributions import Distribution, DistributionType
+from .distributions import _density_key, Distribution, DistributionType
 from .frontend import TranspilerError
 
 FunctionLike = Union[Callable, str]
@@ -70,17 +70,20 @@ def _function_key(fn):
 
 
 def _distribution_key(d: Distribution):
-    """Identity of a Distribution for the plan cache: its type, its parameters, the fingerprint of its density closure (code
-    object + every captured value, as for integrands) and the identities of its table arrays -- by value where a value exists, so
-    that `Distribution.normal(0, 1)` written inline in every call (the reference's examples and benchmark do) finds the plan of the
-    previous call instead of building and caching a new one each time. A density that cannot be fingerprinted falls back to the
-    object's identity (the cache entry keeps the object alive, so an id() cannot be reused while the entry exists). Writing into
-    a table array IN PLACE after it has been used is not seen: tables are treated as immutable once a call has seen them."""
+    """Identity of a Distribution for the plan cache: its type, its parameters, the value of its density closure (code object +
+    captured values + the globals it names, where all of those are plain values: distributions._density_key -- a few attribute
+    reads, no source is parsed) and the identities of its table arrays. By value where a value exists, so that
+    `Distribution.normal(0, 1)` written inline in every call (the reference's examples and benchmark do) finds the plan of the
+    previous call instead of building and caching a new one each time. A density without such a value (it captures arrays, say:
+    from_pdf_table) falls back to the object's identity (the cache entry keeps the object alive, so an id() cannot be reused while
+    the entry exists). Writing into a table array IN PLACE after it has been used is not seen: tables are treated as immutable once
+    a call has seen them."""
     p = d.params
     try:
-        density = frontend.fingerprint(d._pdf_func)
-        hash(density)
-    except (TypeError, AttributeError, ValueError, TranspilerError):
+        density = _density_key(d._pdf_func)
+    except (TypeError, ValueError):
+        density = None
+    if density is None:
         density = (id(d), id(d._pdf_func))
     return (d.dist_type, tuple(p.items()) if p else None, density, id(d._x_table), id(d._cdf_table), id(d._pdf_table))
 
