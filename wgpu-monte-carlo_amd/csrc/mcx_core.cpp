@@ -22,17 +22,23 @@
 
 namespace {
 
-uint64_t fnv(const void* data, size_t n, uint64_t h) {
-    const unsigned char* p = (const unsigned char*)data;
-    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
-    return h;
-}
-const uint64_t kSeedA = 14695981039346656037ull, kSeedB = 0x9E3779B97F4A7C15ull;
+// 128 bits of content hash, eight bytes at a time (two independent multiply-xorshift lanes; not cryptographic: it names a cache entry)
 struct Key { uint64_t a, b; bool operator==(const Key& o) const { return a == o.a && b == o.b; } };
 struct KeyHash { size_t operator()(const Key& k) const { return (size_t)(k.a ^ (k.b * 0x9E3779B97F4A7C15ull)); } };
 struct Hasher {
-    uint64_t a = kSeedA, b = kSeedB;
-    void add(const void* p, size_t n) { a = fnv(p, n, a); b = fnv(p, n, b); }
+    uint64_t a = 14695981039346656037ull, b = 0x9E3779B97F4A7C15ull;
+    void word(uint64_t w) {
+        a = (a ^ w) * 0x100000001B3ull;            a ^= a >> 32;
+        b = (b + w) * 0xD6E8FEB86659FD93ull;       b ^= b >> 29;
+    }
+    void add(const void* p, size_t n) {
+        const unsigned char* c = (const unsigned char*)p;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, c + i, 8); word(w); }
+        uint64_t tail = 0;
+        if (i < n) memcpy(&tail, c + i, n - i);
+        word(tail ^ ((uint64_t)n << 56));          // the length closes the run: "ab" + "c" and "a" + "bc" differ
+    }
     template <class T> void pod(const T& v) { add(&v, sizeof v); }
     Key key() const { return {a, b}; }
 };

@@ -41,6 +41,7 @@ from . import runtime
 _CORES: dict = {}            # (device, math) -> mcx_core handle: every integrator of a process shares the engine, the resident tables and
 _CORES_LOCK = threading.Lock()   # the compiled modules of its device (the reference's convenience functions build an integrator per call)
 _MATH = {"precise": 0, "default": 1, "fast": 2}
+_ENCODED: dict = {}          # tuple of WGSL strings -> the char* array handed to libmcx; bounded, oldest out
 
 _DIST = {"uniform": runtime.DIST_UNIFORM, "normal": runtime.DIST_NORMAL, "exponential": runtime.DIST_EXPONENTIAL,
          "custom": runtime.DIST_CUSTOM}
@@ -125,9 +126,17 @@ class MonteCarloIntegrator:
     def _strings(functions):
         if len(functions) == 0:
             raise ValueError("At least one function is required")          # src/lib.rs:61-65
+        try:
+            return _ENCODED[tuple(functions)]                              # the reference's Python half sends the same texts call after call
+        except (KeyError, TypeError):
+            pass
         if not all(isinstance(f, str) for f in functions):
             raise TypeError("functions must be WGSL strings")
-        return (C.c_char_p * len(functions))(*[f.encode() for f in functions])
+        texts = (C.c_char_p * len(functions))(*[f.encode() for f in functions])
+        if len(_ENCODED) >= 256:
+            _ENCODED.pop(next(iter(_ENCODED)), None)
+        _ENCODED[tuple(functions)] = texts
+        return texts
 
     @staticmethod
     def _tables(x_table, cdf_table, target_x, target_v, proposal_x, proposal_v):
